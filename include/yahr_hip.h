@@ -1,0 +1,246 @@
+/*
+ * yahr_hip.h -- C ABI of libyahr_hip.so: the MI355X (gfx950) render hot path of pstiasny/yahr.
+ *
+ * The reference (Haskell) has no FFI; the seam this library replaces is internal to main.hs:
+ *
+ *     render / renderEval / renderPar :: Int -> Int -> [[SampleCoordinates]]
+ *                                     -> (Float -> Float -> Ray) -> (Ray -> Spectrum) -> [Sample]
+ *                                                                   (main.hs:68-96, selected at :133-137)
+ *
+ * with the two closures (caster = Cameras.computeInitialRay camera, main.hs:121; li = Integrators.radiance
+ * integ lights collider, main.hs:125-126) replaced by plain data: `yahr_scene`.  Everything is extern "C",
+ * plain pointers and sizes, no exceptions, no callbacks, no torch types.  INTEGRATION.md shows the
+ * `foreign import ccall` stub a yahr maintainer would add.
+ *
+ * Layers (each usable on its own):
+ *   1. yahr_scene            flattened scene: camera matrices, BVH nodes in reference DFS order,
+ *                            leaf-ordered primitive records, materials, lights.   <- what the kernel eats
+ *   2. yahr_host_scene       C++ host mirror of Scene.hs / main.hs:41-60 / Culling.hs: .yahrr loader
+ *                            (derived-Read grammar), expand, BVH build -> produces (1)
+ *   3. yahr_ctx              a scene resident in one GPU's HBM + render launches on a HIP stream
+ *   4. one-shot conveniences yahr_render_rows / yahr_render_multi (host buffers in, host image out)
+ *
+ * Conventions: return 0 (YAHR_OK) on success, negative code otherwise; yahr_last_error() gives the message
+ * (thread-local).  Inputs are caller-owned and read-only for the duration of the call.  A yahr_ctx is
+ * thread-compatible: one call at a time per context.
+ */
+#ifndef YAHR_HIP_H
+#define YAHR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YAHR_ABI_VERSION 1
+
+enum {
+  YAHR_OK = 0,
+  YAHR_E_ARG = -1,       /* bad argument / malformed yahr_scene */
+  YAHR_E_PARSE = -2,     /* .yahrr text rejected ("Prelude.read: no parse", main.hs:117) */
+  YAHR_E_IO = -3,        /* file could not be read / written */
+  YAHR_E_HIP = -4,       /* HIP runtime error */
+  YAHR_E_NOMEM = -5,
+  YAHR_E_NODEVICE = -6,  /* no usable gfx950 device / kernel image missing */
+  YAHR_E_MATERIAL = -7   /* a ray shaded an object whose materialId is not in the map (Map.!, main.hs:55) */
+};
+
+/* ---------------------------------------------------------------------------------------------
+ * 1. Flattened scene
+ * ------------------------------------------------------------------------------------------- */
+
+/* BVH node, 32 B.  Nodes are stored in the reference's DFS (pre)order: Culling.hs:38 visits the left
+ * child, then the right one, so the left child of interior node i is node i+1.
+ *   interior : b == -1, a = index of the first node after this node's subtree ("skip" link)
+ *   leaf     : b >= 0 = index of its first primitive record, a = number of primitives
+ *              (a == 1: `wrapCollider col bb`, Culling.hs:33;  a > 1: multiLeaf, Culling.hs:52-54;
+ *               a == 0: the null collider of Culling.hs:32, box = AABBs.empty)
+ * lo/hi = BoundingBox min/max (AABBs.hs:8). */
+typedef struct yahr_node {
+  float lo[3]; int32_t a;
+  float hi[3]; int32_t b;
+} yahr_node;
+
+/* Primitive record in LEAF order, 48 B (so a leaf's primitives are contiguous).
+ *   kind 0 triangle (Shapes.hs:36-59): p0, e1 = p1 - p0, e2 = p2 - p0 (computed in binary32)
+ *   kind 1 sphere   (Shapes.hs:13-29): p0 = centre, e1[0] = radius
+ * mat  = index into mats, or -1 for an unknown materialId.  orig = index in `objects >>= expand` order
+ * (main.hs:44). */
+typedef struct yahr_prim {
+  float p0[3]; int32_t mat;
+  float e1[3]; int32_t kind;
+  float e2[3]; int32_t orig;
+} yahr_prim;
+
+/* Triangle vertex normals n0,n1,n2 (Scene.hs:20-28) for primitive record i; unused for spheres. 48 B. */
+typedef struct yahr_prim_normals {
+  float n0[3]; float pad0;
+  float n1[3]; float pad1;
+  float n2[3]; float pad2;
+} yahr_prim_normals;
+
+/* blinnPhong ambient diffuse specular shininess (Shaders.hs:12-14); ambient is ignored there. 32 B. */
+typedef struct yahr_material {
+  float diffuse[3]; float shininess;
+  float specular[3]; float pad;
+} yahr_material;
+
+/* PointLight position spectrum (Lights.hs:7). 32 B. */
+typedef struct yahr_light {
+  float pos[3]; float pad0;
+  float spectrum[3]; float pad1;
+} yahr_light;
+
+typedef struct yahr_scene {
+  int32_t abi_version;          /* YAHR_ABI_VERSION */
+  int32_t width, height;        /* floor imW, floor imH (main.hs:122-123) */
+  int32_t depth;                /* WhittedIntegrator recursionDepth (Integrators.hs:18-20) */
+  float cam_tf[16];             /* cameraToWorld, row-major (Cameras.hs:58-65) */
+  float cam_vtf[16];            /* tf !*! rasterToCamera (Cameras.hs:81) */
+  float focal;                  /* focalLength */
+  int32_t n_nodes;  const yahr_node *nodes;
+  int32_t n_prims;  const yahr_prim *prims; const yahr_prim_normals *normals;
+  int32_t n_mats;   const yahr_material *mats;
+  int32_t n_lights; const yahr_light *lights;
+} yahr_scene;
+
+/* ---------------------------------------------------------------------------------------------
+ * 2. Host scene: loader, expand, BVH build  (Scene.hs, main.hs:41-60, Culling.hs:21-112)
+ * ------------------------------------------------------------------------------------------- */
+
+typedef struct yahr_host_scene yahr_host_scene;
+
+enum { YAHR_SPLIT_MIDPOINT = 0, YAHR_SPLIT_SAH = 1 };   /* Culling.hs:18 */
+
+/* readFile + `read :: Scene` (main.hs:115-117).  lenient != 0 additionally accepts the stale bundled
+ * scene.yahrr dialect (PointLight with one argument, TriangleMesh without the Normals/Smooth fields). */
+int yahr_scene_load(const char *path, int lenient, yahr_host_scene **out);
+int yahr_scene_parse(const char *text, size_t len, int lenient, yahr_host_scene **out);
+
+/* programmatic assembly: what a foreign host marshals instead of text */
+int yahr_scene_new(yahr_host_scene **out);
+int yahr_scene_set_camera(yahr_host_scene *s, float imW, float imH, float focal,
+                          const float look[3], const float up[3], const float pos[3]);   /* Cameras.hs:54-56 */
+int yahr_scene_set_integrator(yahr_host_scene *s, int32_t recursion_depth);
+int yahr_scene_set_culling(yahr_host_scene *s, int32_t max_depth, int32_t split_mode);
+int yahr_scene_add_material(yahr_host_scene *s, const char *id, const float ambient[3],
+                            const float diffuse[3], const float specular[3], float shininess);
+int yahr_scene_add_light(yahr_host_scene *s, const float pos[3], const float spectrum[3]);
+int yahr_scene_add_sphere(yahr_host_scene *s, const float centre[3], float radius, const char *material_id);
+int yahr_scene_add_triangle(yahr_host_scene *s, const float p0[3], const float p1[3], const float p2[3],
+                            const float n0[3], const float n1[3], const float n2[3], const char *material_id);
+/* TriangleMesh (Scene.hs:29-36): normals NULL = Nothing, smooth NULL = Nothing.  tris = n_tris*3 indices. */
+int yahr_scene_add_mesh(yahr_host_scene *s, int32_t n_points, const float *points, const float *normals,
+                        int32_t n_tris, const int32_t *tris, const uint8_t *smooth, int32_t n_smooth,
+                        const char *material_id);
+/* Subsampled (Scene.hs:37-40): objects added between begin/end are its subsampledObjects (nestable). */
+int yahr_scene_begin_subsampled(yahr_host_scene *s, float subsample_size);
+int yahr_scene_end_subsampled(yahr_host_scene *s);
+
+/* `objects >>= expand`, buildCollisionModel, cull: fills the flattened arrays.  Idempotent. */
+int yahr_scene_build(yahr_host_scene *s);
+/* view of the flattened scene (valid until the host scene is modified or freed); builds if needed */
+const yahr_scene *yahr_scene_flat(yahr_host_scene *s);
+/* scene-file fields that are not in yahr_scene */
+int yahr_scene_info(const yahr_host_scene *s, float *imW, float *imH, int32_t *bvh_depth,
+                    int32_t *split_mode, int32_t *n_objects);
+void yahr_scene_free(yahr_host_scene *s);
+
+/* Sampling.hs:9-21 batchWindow -> out = {x0, y0, x1, y1};  main.hs:128-130 nBatches */
+void yahr_batch_window(int32_t w, int32_t h, int32_t num, int32_t count, int32_t out[4]);
+int32_t yahr_n_batches(int32_t num_threads, int32_t width, int32_t height);
+
+/* ---------------------------------------------------------------------------------------------
+ * 3. Device context and render
+ * ------------------------------------------------------------------------------------------- */
+
+typedef struct yahr_ctx yahr_ctx;
+
+enum {
+  YAHR_TRAVERSE_AUTO = 0,      /* library default */
+  YAHR_TRAVERSE_LANE = 1,      /* every lane walks the node array on its own (vector loads) */
+  YAHR_TRAVERSE_PACKET = 2,    /* the wavefront walks the union of its lanes' paths (scalar node loads) */
+  YAHR_TRAVERSE_HYBRID = 3     /* packet for primary and shadow rays, per-lane for reflection rays */
+};
+enum {
+  YAHR_TILES_WAVE = 0,         /* 8x8-pixel tile per wavefront */
+  YAHR_TILES_REFERENCE = 1     /* the reference's squareBatches windows (Sampling.hs:5-21), one per wavefront */
+};
+
+typedef struct yahr_render_opts {
+  int32_t spp;                 /* 1 = the reference's sampling (pixel corner, main.hs:73). >1: build extension */
+  uint32_t seed;               /* sampler seed (spp > 1 only) */
+  int32_t traverse;            /* YAHR_TRAVERSE_* */
+  int32_t tiles;               /* YAHR_TILES_* */
+  int32_t n_batches;           /* for YAHR_TILES_REFERENCE; 0 = yahr_n_batches(1, w, h) */
+  int32_t collect_stats;       /* != 0: also count box/primitive tests (slower kernel variant) */
+  /* row sharding: the image is cut into strips of strip_rows rows; this call renders the strips s with
+   * s % n_shards == shard, compacted top to bottom into the output.  n_shards <= 1: rows [row0,row1). */
+  int32_t n_shards, shard, strip_rows;
+  int32_t reserved[7];
+} yahr_render_opts;
+
+typedef struct yahr_stats {
+  uint64_t primary_rays, reflection_rays, shadow_rays;   /* rays actually cast */
+  uint64_t box_tests, tri_tests, sphere_tests;           /* per-ray counts (collect_stats only) */
+  uint64_t shaded_hits;
+  uint64_t wave_node_steps, wave_prim_steps;             /* wavefront-level loop trips (collect_stats only) */
+  uint64_t bad_material;                                 /* shaded hits on mat == -1 */
+  double kernel_ms;                                      /* device time of the render launch(es), HIP events */
+  double upload_ms;                                      /* one-shot calls: host->device scene copy */
+} yahr_stats;
+
+void yahr_default_opts(yahr_render_opts *o);
+int yahr_device_count(void);
+
+/* Upload a flattened scene to `device` (index as seen by this process).  The context owns device memory. */
+int yahr_ctx_create(const yahr_scene *scene, int device, yahr_ctx **out);
+void yahr_ctx_destroy(yahr_ctx *ctx);
+
+/* number of image rows shard `shard` of `n_shards` owns with strips of strip_rows rows */
+int32_t yahr_shard_rows(int32_t height, int32_t n_shards, int32_t shard, int32_t strip_rows);
+/* global image row of local row `local` of that shard */
+int32_t yahr_shard_global_row(int32_t local, int32_t n_shards, int32_t shard, int32_t strip_rows);
+
+/* Render rows [row0,row1) (or this shard's strips when opts->n_shards > 1; row0/row1 then ignored) into
+ * DEVICE memory d_rgb: float RGB, index ((local_row)*width + u)*3 -- the reference's `w*v+u` scatter
+ * (main.hs:100) restricted to the rows rendered.  Asynchronous on `hip_stream` (a hipStream_t, NULL =
+ * default stream); no host synchronisation, no allocation: usable inside hipGraph capture. */
+int yahr_ctx_render(yahr_ctx *ctx, int32_t row0, int32_t row1, const yahr_render_opts *opts,
+                    float *d_rgb, void *hip_stream);
+/* Counters of the launches since the last call (synchronises the device). */
+int yahr_ctx_stats(yahr_ctx *ctx, yahr_stats *out);
+
+/* Test/diagnostic entry points: run the device functions on arbitrary rays (host buffers, synchronous).
+ * rays: n*7 floats (x0, u, tMax).  closest hit -> prim_orig (or -1) and t;  radiance -> n*3 floats. */
+int yahr_ctx_trace(yahr_ctx *ctx, int32_t n, const float *rays, int32_t traverse, int32_t *prim_orig, float *t);
+int yahr_ctx_occluded(yahr_ctx *ctx, int32_t n, const float *rays, int32_t traverse, int32_t *blocked);
+int yahr_ctx_radiance(yahr_ctx *ctx, int32_t n, const float *rays, int32_t traverse, float *rgb);
+int yahr_ctx_camera_rays(yahr_ctx *ctx, int32_t n, const float *uv, float *rays);
+
+/* ---------------------------------------------------------------------------------------------
+ * 4. One-shot conveniences (host memory in, host memory out, synchronous)
+ * ------------------------------------------------------------------------------------------- */
+
+/* rgb_out: (rows rendered)*width*3 floats on the HOST. */
+int yahr_render_rows(const yahr_scene *scene, int32_t row0, int32_t row1, int device,
+                     const yahr_render_opts *opts, float *rgb_out, yahr_stats *stats_or_null);
+/* whole image on n_devices GPUs of this process (strips dealt round-robin, assembled on the host).
+ * The multi-process / RCCL form of the same sharding is driven from the host language (see bench.py). */
+int yahr_render_multi(const yahr_scene *scene, int n_devices, const yahr_render_opts *opts,
+                      float *rgb_out, yahr_stats *stats_or_null);
+
+/* Image output (main.hs:142 savePngImage (ImageRGBF img)); 8-bit rule: clamp to [0,1], *255, truncate. */
+int yahr_write_png(const char *path, const float *rgb, int32_t width, int32_t height);
+int yahr_write_ppm(const char *path, const float *rgb, int32_t width, int32_t height);
+int yahr_write_pfm(const char *path, const float *rgb, int32_t width, int32_t height);
+
+const char *yahr_last_error(void);
+const char *yahr_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YAHR_HIP_H */

@@ -1,0 +1,381 @@
+// abi_device.cpp -- device part of the C ABI (include/yahr_hip.h sections 3 and 4): a scene resident in
+// one GPU's HBM, render launches on a caller-supplied HIP stream, diagnostic ray queries, and the
+// one-shot host-buffer conveniences.  There is NO CPU fallback: without a usable HIP device every entry
+// point here fails with YAHR_E_NODEVICE / YAHR_E_HIP.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "host_scene.hpp"
+#include "render_kernel.hpp"
+
+using yahr::set_error;
+
+struct yahr_ctx {
+  int device = 0;
+  DScene ds{};
+  int width = 0, height = 0;
+  void *d_nodes = nullptr, *d_prims = nullptr, *d_normals = nullptr, *d_mats = nullptr, *d_lights = nullptr;
+  unsigned long long *d_ctr = nullptr;
+  int4 *d_windows = nullptr; int n_windows = 0, windows_w = 0, windows_h = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timed = false;
+  double upload_ms = 0;
+};
+
+namespace {
+
+#define HIP_TRY(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                        \
+      return (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice) ? YAHR_E_NODEVICE : YAHR_E_HIP; \
+    }                                                                                      \
+  } while (0)
+
+int check_scene(const yahr_scene *s) {
+  if (!s) { set_error("null scene"); return YAHR_E_ARG; }
+  if (s->abi_version != YAHR_ABI_VERSION) { set_error("yahr_scene.abi_version mismatch"); return YAHR_E_ARG; }
+  if (s->width < 0 || s->height < 0 || s->depth < 0 || s->n_nodes < 0 || s->n_prims < 0 || s->n_mats < 0 || s->n_lights < 0) {
+    set_error("negative count in yahr_scene"); return YAHR_E_ARG;
+  }
+  if ((s->n_nodes && !s->nodes) || (s->n_prims && (!s->prims || !s->normals)) || (s->n_mats && !s->mats) || (s->n_lights && !s->lights)) {
+    set_error("null array in yahr_scene"); return YAHR_E_ARG;
+  }
+  // The kernel trusts the topology: validate it here so a malformed scene cannot fault the GPU.
+  for (int32_t i = 0; i < s->n_nodes; ++i) {
+    const yahr_node &nd = s->nodes[i];
+    if (nd.b >= 0) {
+      if (nd.a < 0 || (int64_t)nd.b + nd.a > s->n_prims) { set_error("leaf primitive range out of bounds at node " + std::to_string(i)); return YAHR_E_ARG; }
+    } else if (nd.b == -1) {
+      if (nd.a <= i || nd.a > s->n_nodes) { set_error("skip link not forward at node " + std::to_string(i)); return YAHR_E_ARG; }
+    } else { set_error("bad node tag at node " + std::to_string(i)); return YAHR_E_ARG; }
+  }
+  for (int32_t i = 0; i < s->n_prims; ++i) {
+    const yahr_prim &p = s->prims[i];
+    if ((p.kind != 0 && p.kind != 1) || p.mat < -1 || p.mat >= s->n_mats) { set_error("bad primitive record " + std::to_string(i)); return YAHR_E_ARG; }
+  }
+  return YAHR_OK;
+}
+
+int upload(void **dst, const void *src, size_t bytes) {
+  *dst = nullptr;
+  if (bytes == 0) bytes = 16;   // keep pointers non-null
+  HIP_TRY(hipMalloc(dst, bytes));
+  if (src) HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+  return YAHR_OK;
+}
+
+int pick_mode(int traverse) {
+  switch (traverse) {
+    case YAHR_TRAVERSE_LANE: return TRAV_LANE;
+    case YAHR_TRAVERSE_PACKET: return TRAV_PACKET;
+    case YAHR_TRAVERSE_HYBRID: return TRAV_HYBRID;
+    default: return TRAV_HYBRID;    // YAHR_TRAVERSE_AUTO
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+void yahr_default_opts(yahr_render_opts *o) {
+  if (!o) return;
+  std::memset(o, 0, sizeof *o);
+  o->spp = 1; o->traverse = YAHR_TRAVERSE_AUTO; o->tiles = YAHR_TILES_WAVE; o->n_shards = 1; o->strip_rows = 8;
+}
+
+int yahr_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int32_t yahr_shard_rows(int32_t height, int32_t n_shards, int32_t shard, int32_t strip_rows) {
+  if (n_shards <= 1) return height;
+  if (strip_rows <= 0 || shard < 0 || shard >= n_shards) return 0;
+  int32_t rows = 0;
+  for (int32_t s = shard; (int64_t)s * strip_rows < height; s += n_shards) {
+    int32_t r0 = s * strip_rows, r1 = r0 + strip_rows;
+    rows += (r1 > height ? height : r1) - r0;
+  }
+  return rows;
+}
+int32_t yahr_shard_global_row(int32_t local, int32_t n_shards, int32_t shard, int32_t strip_rows) {
+  if (n_shards <= 1) return local;
+  int32_t k = local / strip_rows;
+  return (k * n_shards + shard) * strip_rows + (local - k * strip_rows);
+}
+
+int yahr_ctx_create(const yahr_scene *s, int device, yahr_ctx **out) {
+  if (!out) { set_error("null argument"); return YAHR_E_ARG; }
+  *out = nullptr;
+  int rc = check_scene(s);
+  if (rc != YAHR_OK) return rc;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0) { set_error("no HIP device available (libyahr_hip has no CPU fallback)"); return YAHR_E_NODEVICE; }
+  if (device < 0 || device >= ndev) { set_error("device index out of range"); return YAHR_E_NODEVICE; }
+  HIP_TRY(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    set_error(std::string("device is ") + prop.gcnArchName + ", this library carries gfx950 code only"); return YAHR_E_NODEVICE;
+  }
+  auto *c = new yahr_ctx();
+  c->device = device; c->width = s->width; c->height = s->height;
+  hipEvent_t u0, u1;
+  HIP_TRY(hipEventCreate(&u0)); HIP_TRY(hipEventCreate(&u1));
+  HIP_TRY(hipEventRecord(u0, nullptr));
+  if ((rc = upload(&c->d_nodes, s->nodes, sizeof(yahr_node) * (size_t)s->n_nodes)) ||
+      (rc = upload(&c->d_prims, s->prims, sizeof(yahr_prim) * (size_t)s->n_prims)) ||
+      (rc = upload(&c->d_normals, s->normals, sizeof(yahr_prim_normals) * (size_t)s->n_prims)) ||
+      (rc = upload(&c->d_mats, s->mats, sizeof(yahr_material) * (size_t)s->n_mats)) ||
+      (rc = upload(&c->d_lights, s->lights, sizeof(yahr_light) * (size_t)s->n_lights)) ||
+      (rc = upload((void **)&c->d_ctr, nullptr, sizeof(unsigned long long) * CTR_COUNT))) {
+    yahr_ctx_destroy(c); return rc;
+  }
+  HIP_TRY(hipMemset(c->d_ctr, 0, sizeof(unsigned long long) * CTR_COUNT));
+  HIP_TRY(hipEventRecord(u1, nullptr));
+  HIP_TRY(hipEventSynchronize(u1));
+  float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, u0, u1)); c->upload_ms = ms;
+  hipEventDestroy(u0); hipEventDestroy(u1);
+  HIP_TRY(hipEventCreate(&c->ev0)); HIP_TRY(hipEventCreate(&c->ev1));
+  DScene &d = c->ds;
+  d.nodes = (const float4 *)c->d_nodes; d.prims = (const float4 *)c->d_prims; d.normals = (const float4 *)c->d_normals;
+  d.mats = (const float4 *)c->d_mats; d.lights = (const float4 *)c->d_lights;
+  d.n_nodes = s->n_nodes; d.n_prims = s->n_prims; d.n_mats = s->n_mats; d.n_lights = s->n_lights;
+  d.depth = s->depth;
+  // origin = transformPoint tf (Vec3 0 0 0)  (Cameras.hs:84), same left fold as the device's transform_point
+  {
+    float tv[4];
+    for (int i = 0; i < 4; ++i) {
+      float acc = 0.0f;
+      acc = acc + s->cam_tf[i * 4 + 0] * 0.0f; acc = acc + s->cam_tf[i * 4 + 1] * 0.0f;
+      acc = acc + s->cam_tf[i * 4 + 2] * 0.0f; acc = acc + s->cam_tf[i * 4 + 3] * 1.0f;
+      tv[i] = acc;
+    }
+    float iw = 1.0f / tv[3];
+    d.origin[0] = iw * tv[0]; d.origin[1] = iw * tv[1]; d.origin[2] = iw * tv[2];
+  }
+  std::memcpy(d.vtf, s->cam_vtf, sizeof d.vtf);
+  d.focal = s->focal;
+  *out = c;
+  return YAHR_OK;
+}
+
+void yahr_ctx_destroy(yahr_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipFree(c->d_nodes); (void)hipFree(c->d_prims); (void)hipFree(c->d_normals); (void)hipFree(c->d_mats);
+  (void)hipFree(c->d_lights); (void)hipFree(c->d_ctr); (void)hipFree(c->d_windows);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  delete c;
+}
+
+// Prepare the reference's squareBatches windows on the device (outside any capture).
+static int ensure_windows(yahr_ctx *c, int n_batches) {
+  if (c->d_windows && c->n_windows == n_batches && c->windows_w == c->width && c->windows_h == c->height) return YAHR_OK;
+  std::vector<int4> win((size_t)n_batches);
+  for (int b = 0; b < n_batches; ++b) {
+    int32_t w4[4]; yahr_batch_window(c->width, c->height, b, n_batches, w4);
+    win[(size_t)b] = make_int4(w4[0], w4[1], w4[2], w4[3]);
+  }
+  if (c->d_windows) { HIP_TRY(hipFree(c->d_windows)); c->d_windows = nullptr; }
+  HIP_TRY(hipMalloc((void **)&c->d_windows, sizeof(int4) * (size_t)n_batches));
+  HIP_TRY(hipMemcpy(c->d_windows, win.data(), sizeof(int4) * (size_t)n_batches, hipMemcpyHostToDevice));
+  c->n_windows = n_batches; c->windows_w = c->width; c->windows_h = c->height;
+  return YAHR_OK;
+}
+
+int yahr_ctx_render(yahr_ctx *c, int32_t row0, int32_t row1, const yahr_render_opts *opts_in, float *d_rgb, void *hip_stream) {
+  if (!c || !d_rgb) { set_error("null argument"); return YAHR_E_ARG; }
+  yahr_render_opts o; if (opts_in) o = *opts_in; else yahr_default_opts(&o);
+  if (o.spp < 1) { set_error("spp must be >= 1"); return YAHR_E_ARG; }
+  hipStream_t st = (hipStream_t)hip_stream;
+  HIP_TRY(hipSetDevice(c->device));
+  RParams rp{};
+  rp.width = c->width; rp.height = c->height;
+  rp.spp = o.spp; rp.seed = o.seed;
+  { int n = (int)std::floor(std::sqrt((double)o.spp) + 0.5); rp.n_strata = (n * n == o.spp) ? n : 1; }
+  rp.xcd_swizzle = 1;
+  int n_blocks = 0;
+  if (o.tiles == YAHR_TILES_REFERENCE) {
+    if (o.n_shards > 1 || row0 != 0 || row1 != c->height) { set_error("reference tiles render the whole image only"); return YAHR_E_ARG; }
+    int nb = o.n_batches > 0 ? o.n_batches : yahr_n_batches(1, c->width, c->height);
+    int rc = ensure_windows(c, nb); if (rc) return rc;
+    rp.tile_mode = 1; rp.windows = c->d_windows; rp.n_local_rows = c->height; rp.strip_rows = c->height > 0 ? c->height : 1; rp.n_shards = 1;
+    n_blocks = nb;
+  } else {
+    if (o.n_shards > 1) {
+      if (o.shard < 0 || o.shard >= o.n_shards || o.strip_rows <= 0) { set_error("bad shard spec"); return YAHR_E_ARG; }
+      rp.n_shards = o.n_shards; rp.strip_rows = o.strip_rows; rp.row0 = o.shard * o.strip_rows;
+      rp.n_local_rows = yahr_shard_rows(c->height, o.n_shards, o.shard, o.strip_rows);
+    } else {
+      if (row0 < 0 || row1 > c->height || row0 > row1) { set_error("bad row range"); return YAHR_E_ARG; }
+      rp.n_shards = 1; rp.row0 = row0; rp.n_local_rows = row1 - row0;
+      rp.strip_rows = rp.n_local_rows > 0 ? rp.n_local_rows : 1;
+    }
+    rp.tile_mode = 0;
+    rp.tiles_x = (c->width + 7) / 8;
+    rp.n_tiles = rp.tiles_x * ((rp.n_local_rows + 7) / 8);
+    n_blocks = ((rp.n_tiles + 7) / 8) * 8;     // the XCD swizzle needs a multiple of 8 blocks
+  }
+  if (n_blocks == 0 || c->width == 0) return YAHR_OK;
+  HIP_TRY(hipEventRecord(c->ev0, st));
+  HIP_TRY(yahr_dev::launch_render(c->ds, rp, pick_mode(o.traverse), n_blocks, d_rgb, c->d_ctr, o.collect_stats != 0, st));
+  HIP_TRY(hipEventRecord(c->ev1, st));
+  c->timed = true;
+  return YAHR_OK;
+}
+
+int yahr_ctx_stats(yahr_ctx *c, yahr_stats *out) {
+  if (!c || !out) { set_error("null argument"); return YAHR_E_ARG; }
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipDeviceSynchronize());
+  unsigned long long h[CTR_COUNT];
+  HIP_TRY(hipMemcpy(h, c->d_ctr, sizeof h, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemset(c->d_ctr, 0, sizeof h));
+  std::memset(out, 0, sizeof *out);
+  out->primary_rays = h[CTR_PRIMARY]; out->reflection_rays = h[CTR_REFLECTION]; out->shadow_rays = h[CTR_SHADOW];
+  out->shaded_hits = h[CTR_SHADED]; out->bad_material = h[CTR_BAD_MAT];
+  out->box_tests = h[CTR_BOX]; out->tri_tests = h[CTR_TRI]; out->sphere_tests = h[CTR_SPH];
+  out->wave_node_steps = h[CTR_WAVE_NODES]; out->wave_prim_steps = h[CTR_WAVE_PRIMS];
+  if (c->timed) { float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1)); out->kernel_ms = ms; }
+  out->upload_ms = c->upload_ms;
+  if (out->bad_material) {
+    set_error("Map.!: given key is not an element in the map (an object with an unknown materialId was shaded)");
+    return YAHR_E_MATERIAL;
+  }
+  return YAHR_OK;
+}
+
+static int ray_query(yahr_ctx *c, int32_t n, const float *rays, int which, int traverse, int32_t *iout, float *fout) {
+  if (!c || n < 0 || (n && !rays)) { set_error("bad ray query arguments"); return YAHR_E_ARG; }
+  if (n == 0) return YAHR_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  float *d_rays = nullptr; int *d_i = nullptr; float *d_f = nullptr;
+  HIP_TRY(hipMalloc((void **)&d_rays, sizeof(float) * 7 * (size_t)n));
+  HIP_TRY(hipMemcpy(d_rays, rays, sizeof(float) * 7 * (size_t)n, hipMemcpyHostToDevice));
+  int mode = pick_mode(traverse);
+  int rc = YAHR_OK;
+  if (which == 2) {
+    HIP_TRY(hipMalloc((void **)&d_f, sizeof(float) * 3 * (size_t)n));
+    HIP_TRY(yahr_dev::launch_radiance(c->ds, mode, n, d_rays, d_f, c->d_ctr, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(fout, d_f, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost));
+  } else {
+    if (mode == TRAV_HYBRID) mode = TRAV_PACKET;
+    HIP_TRY(hipMalloc((void **)&d_i, sizeof(int) * (size_t)n));
+    HIP_TRY(hipMalloc((void **)&d_f, sizeof(float) * (size_t)n));
+    HIP_TRY(yahr_dev::launch_trace(c->ds, mode, n, d_rays, which == 1, d_i, d_f, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(iout, d_i, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+    if (fout) HIP_TRY(hipMemcpy(fout, d_f, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
+  }
+  (void)hipFree(d_rays); (void)hipFree(d_i); (void)hipFree(d_f);
+  return rc;
+}
+
+int yahr_ctx_trace(yahr_ctx *c, int32_t n, const float *rays, int32_t traverse, int32_t *prim_orig, float *t) {
+  if (n && !prim_orig) { set_error("null output"); return YAHR_E_ARG; }
+  return ray_query(c, n, rays, 0, traverse, prim_orig, t);
+}
+int yahr_ctx_occluded(yahr_ctx *c, int32_t n, const float *rays, int32_t traverse, int32_t *blocked) {
+  if (n && !blocked) { set_error("null output"); return YAHR_E_ARG; }
+  int rc = ray_query(c, n, rays, 1, traverse, blocked, nullptr);
+  if (rc == YAHR_OK) for (int32_t i = 0; i < n; ++i) blocked[i] = blocked[i] >= 0 ? 1 : 0;
+  return rc;
+}
+int yahr_ctx_radiance(yahr_ctx *c, int32_t n, const float *rays, int32_t traverse, float *rgb) {
+  if (n && !rgb) { set_error("null output"); return YAHR_E_ARG; }
+  return ray_query(c, n, rays, 2, traverse, nullptr, rgb);
+}
+int yahr_ctx_camera_rays(yahr_ctx *c, int32_t n, const float *uv, float *rays) {
+  if (!c || n < 0 || (n && (!uv || !rays))) { set_error("bad arguments"); return YAHR_E_ARG; }
+  if (n == 0) return YAHR_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  float *d_uv = nullptr, *d_rays = nullptr;
+  HIP_TRY(hipMalloc((void **)&d_uv, sizeof(float) * 2 * (size_t)n));
+  HIP_TRY(hipMalloc((void **)&d_rays, sizeof(float) * 7 * (size_t)n));
+  HIP_TRY(hipMemcpy(d_uv, uv, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice));
+  HIP_TRY(yahr_dev::launch_camera_rays(c->ds, n, d_uv, d_rays, nullptr));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(rays, d_rays, sizeof(float) * 7 * (size_t)n, hipMemcpyDeviceToHost));
+  (void)hipFree(d_uv); (void)hipFree(d_rays);
+  return YAHR_OK;
+}
+
+int yahr_render_rows(const yahr_scene *scene, int32_t row0, int32_t row1, int device,
+                     const yahr_render_opts *opts, float *rgb_out, yahr_stats *stats) {
+  if (!rgb_out) { set_error("null output"); return YAHR_E_ARG; }
+  yahr_ctx *c = nullptr;
+  int rc = yahr_ctx_create(scene, device, &c);
+  if (rc) return rc;
+  yahr_render_opts o; if (opts) o = *opts; else yahr_default_opts(&o);
+  int32_t rows = (o.n_shards > 1) ? yahr_shard_rows(scene->height, o.n_shards, o.shard, o.strip_rows) : (row1 - row0);
+  size_t bytes = sizeof(float) * 3 * (size_t)(rows > 0 ? rows : 0) * (size_t)scene->width;
+  float *d_rgb = nullptr;
+  auto fail = [&](int code) { if (d_rgb) (void)hipFree(d_rgb); yahr_ctx_destroy(c); return code; };
+  if (bytes) {
+    if (hipMalloc((void **)&d_rgb, bytes) != hipSuccess) { set_error("hipMalloc(image) failed"); return fail(YAHR_E_NOMEM); }
+    if (hipMemset(d_rgb, 0, bytes) != hipSuccess) { set_error("hipMemset failed"); return fail(YAHR_E_HIP); }
+    rc = yahr_ctx_render(c, row0, row1, &o, d_rgb, nullptr);
+    if (rc) return fail(rc);
+  }
+  yahr_stats st; rc = yahr_ctx_stats(c, &st);
+  if (stats) *stats = st;
+  if (rc) return fail(rc);
+  if (bytes && hipMemcpy(rgb_out, d_rgb, bytes, hipMemcpyDeviceToHost) != hipSuccess) { set_error("hipMemcpy(image) failed"); return fail(YAHR_E_HIP); }
+  return fail(YAHR_OK);
+}
+
+int yahr_render_multi(const yahr_scene *scene, int n_devices, const yahr_render_opts *opts, float *rgb_out, yahr_stats *stats) {
+  if (!scene || !rgb_out || n_devices < 1) { set_error("bad arguments"); return YAHR_E_ARG; }
+  int have = yahr_device_count();
+  if (have < 1) { set_error("no HIP device available (libyahr_hip has no CPU fallback)"); return YAHR_E_NODEVICE; }
+  if (n_devices > have) { set_error("more devices requested than visible"); return YAHR_E_NODEVICE; }
+  yahr_render_opts base; if (opts) base = *opts; else yahr_default_opts(&base);
+  const int strip = base.strip_rows > 0 ? base.strip_rows : 8;
+  std::vector<int> rcs((size_t)n_devices, 0);
+  std::vector<std::string> errs((size_t)n_devices);
+  std::vector<yahr_stats> sts((size_t)n_devices);
+  std::vector<std::vector<float>> bufs((size_t)n_devices);
+  std::vector<std::thread> th;
+  for (int d = 0; d < n_devices; ++d) {
+    th.emplace_back([&, d] {
+      yahr_render_opts o = base; o.n_shards = n_devices; o.shard = d; o.strip_rows = strip;
+      if (n_devices == 1) { o.n_shards = 1; }
+      int32_t rows = yahr_shard_rows(scene->height, n_devices, d, strip);
+      bufs[(size_t)d].assign((size_t)rows * scene->width * 3, 0.0f);
+      rcs[(size_t)d] = yahr_render_rows(scene, 0, scene->height, d, &o, bufs[(size_t)d].data(), &sts[(size_t)d]);
+      if (rcs[(size_t)d]) errs[(size_t)d] = yahr_last_error();
+    });
+  }
+  for (auto &t : th) t.join();
+  yahr_stats total; std::memset(&total, 0, sizeof total);
+  for (int d = 0; d < n_devices; ++d) {
+    if (rcs[(size_t)d]) { set_error("device " + std::to_string(d) + ": " + errs[(size_t)d]); return rcs[(size_t)d]; }
+    int32_t rows = yahr_shard_rows(scene->height, n_devices, d, strip);
+    for (int32_t lv = 0; lv < rows; ++lv) {
+      int32_t gv = yahr_shard_global_row(lv, n_devices, d, strip);
+      std::memcpy(rgb_out + (size_t)gv * scene->width * 3, bufs[(size_t)d].data() + (size_t)lv * scene->width * 3, sizeof(float) * 3 * (size_t)scene->width);
+    }
+    const yahr_stats &s = sts[(size_t)d];
+    total.primary_rays += s.primary_rays; total.reflection_rays += s.reflection_rays; total.shadow_rays += s.shadow_rays;
+    total.box_tests += s.box_tests; total.tri_tests += s.tri_tests; total.sphere_tests += s.sphere_tests;
+    total.shaded_hits += s.shaded_hits; total.wave_node_steps += s.wave_node_steps; total.wave_prim_steps += s.wave_prim_steps;
+    if (s.kernel_ms > total.kernel_ms) total.kernel_ms = s.kernel_ms;
+    if (s.upload_ms > total.upload_ms) total.upload_ms = s.upload_ms;
+  }
+  if (stats) *stats = total;
+  return YAHR_OK;
+}
+
+}  // extern "C"

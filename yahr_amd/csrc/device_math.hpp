@@ -1,0 +1,158 @@
+// device_math.hpp -- gfx950 device functions of the yahr hot path (binary32, operation order literal to
+// the reference so that results are bit-identical to a non-fused CPU evaluation; the only inexact
+// piece is powf in the Blinn term).  Compiled with -ffp-contract=off and without fast-math:
+// HIP's f32 divide and sqrt are correctly rounded by default.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#pragma clang fp contract(off)
+
+namespace yd {
+
+struct V3 { float x, y, z; };
+
+#define YD __device__ __forceinline__
+
+// ---- Vectors.hs -------------------------------------------------------------------------------
+YD V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+YD V3 vof(float l) { return v3(l, l, l); }                                           // :20-21
+YD V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }          // :24
+YD V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }          // :25
+YD V3 operator*(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }          // :26 component-wise
+YD V3 vneg(V3 a) { return v3(-a.x, -a.y, -a.z); }                                    // :27
+YD float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }             // (.*) :33, + infixl 6
+YD float lensq(V3 v) { return dot(v, v); }                                           // :36-37
+YD float len(V3 v) { return sqrtf(lensq(v)); }                                       // :39-40
+YD V3 scale(float f, V3 v) { return v3(f * v.x, f * v.y, f * v.z); }                 // (@*) :42-43
+YD V3 norm(V3 v) { return scale(1.0f / len(v), v); }                                 // :46-47 reciprocal, 3 muls
+YD V3 cross(V3 a, V3 b) {                                                            // :49-53
+  return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+// Haskell's class-default Ord min/max: NaN-asymmetric (not fminf/fmaxf)
+YD float hmax(float x, float y) { return (x <= y) ? y : x; }
+YD float hmin(float x, float y) { return (x <= y) ? x : y; }
+
+YD V3 xyz(float4 v) { return v3(v.x, v.y, v.z); }
+
+struct Ray { V3 o, d; float tmax; };                                                  // Rays.hs:11
+
+// ---- AABBs.hs:29-40 bbRayIntersection ---------------------------------------------------------
+// inv = 1 / u per axis (the reference recomputes it per box; the value is the same)
+YD bool slab_hit(V3 lo, V3 hi, V3 o, V3 inv, float tmax) {
+  float tnear = 0.0f, tfar = tmax;
+  {
+    float t0 = (lo.x - o.x) * inv.x, t1 = (hi.x - o.x) * inv.x;
+    tnear = hmax(tnear, hmin(t0, t1)); tfar = hmin(tfar, hmax(t0, t1));
+  }
+  {
+    float t0 = (lo.y - o.y) * inv.y, t1 = (hi.y - o.y) * inv.y;
+    tnear = hmax(tnear, hmin(t0, t1)); tfar = hmin(tfar, hmax(t0, t1));
+  }
+  {
+    float t0 = (lo.z - o.z) * inv.z, t1 = (hi.z - o.z) * inv.z;
+    tnear = hmax(tnear, hmin(t0, t1)); tfar = hmin(tfar, hmax(t0, t1));
+  }
+  return !(tnear > tfar);
+}
+
+// ---- Shapes.hs:36-59 collideTriangle, geometric part ---------------------------------------------
+// Returns the conjunction of every acceptance test that does not need the normals; the caller then
+// applies `u .* ns < 0` (Shapes.hs:57).  Short-circuit order does not matter: the tests are pure.
+YD bool tri_candidate(V3 p0, V3 e1, V3 e2, V3 o, V3 u, float tmax, float &t, float &b1, float &b2) {
+  V3 s = o - p0;
+  V3 s1 = cross(u, e2);
+  V3 s2 = cross(s, e1);
+  float inv = 1.0f / dot(s1, e1);
+  t = dot(s2, e2) * inv;
+  b1 = dot(s1, s) * inv;
+  b2 = dot(s2, u) * inv;
+  float b0 = (1.0f - b1) - b2;
+  return b0 >= 0.0f && b0 <= 1.0f && b1 >= 0.0f && b1 <= 1.0f && b2 >= 0.0f && b2 <= 1.0f &&
+         t > 0.0f && t <= tmax;
+}
+YD V3 tri_shading_normal(float b1, float b2, V3 n0, V3 n1, V3 n2) {                  // Shapes.hs:47-48
+  float b0 = (1.0f - b1) - b2;
+  return (scale(b0, n0) + scale(b1, n1)) + scale(b2, n2);
+}
+
+// ---- Shapes.hs:13-29 collideSphere -----------------------------------------------------------------
+YD bool sphere_hit(V3 c, float r, V3 o, V3 u, float tmax, float &t) {
+  V3 d = o - c;
+  float a = dot(u, u);
+  float b = dot(vof(2.0f) * d, u);
+  float cc = dot(d, d) - r * r;
+  float delta = b * b - (4.0f * a) * cc;
+  if (delta < 0.0f) return false;
+  float sq = sqrtf(delta);
+  float t0 = ((-b) - sq) / (2.0f * a);
+  float t1 = ((-b) + sq) / (2.0f * a);
+  if (t0 > 0.0f && t0 <= tmax) { t = t0; return true; }
+  if (t1 > 0.0f && t1 <= tmax) { t = t1; return true; }
+  return false;
+}
+
+// ---- BSDF.hs:12-46 + Shaders.hs:12-14 --------------------------------------------------------------
+#define YD_PI 3.14159274101257324f   /* pi :: Float */
+
+YD V3 loc_lambertian(V3 i, V3 o) {                                                   // BSDF.hs:15-17
+  return (i.z > 0.0f && o.z > 0.0f) ? vof(1.0f / YD_PI) : vof(0.0f);
+}
+YD V3 loc_blinn(float e, V3 i, V3 o) {                                               // BSDF.hs:18-30
+  if (!(i.z > 0.0f && o.z > 0.0f)) return vof(0.0f);
+  V3 h = norm(i + o);
+  float cos_o = fabsf(o.z), cos_i = fabsf(i.z);
+  float cos_h = dot(i, h);
+  float o_dot_h = dot(o, h);
+  float d = ((e + 2.0f) * powf(fabsf(h.z), e)) / (2.0f * YD_PI);
+  float g = hmin(1.0f, hmin(((2.0f * cos_h) * cos_o) / o_dot_h, ((2.0f * cos_h) * cos_i) / o_dot_h));
+  float f = 1.0f;                                                                    // fresnel, BSDF.hs:34
+  return vof(((d * g) * f) / ((4.0f * cos_i) * cos_o));
+}
+
+struct Frame { V3 nn, sn, tn; };                                                      // BSDF.hs:36-38
+YD Frame bsdf_frame(V3 normal, V3 dpdu) {
+  Frame f; f.nn = normal; f.sn = norm(dpdu); f.tn = cross(f.nn, f.sn); return f;
+}
+YD V3 world_to_loc(const Frame &f, V3 v) { return v3(dot(v, f.sn), dot(v, f.tn), dot(v, f.nn)); }  // :40
+
+// Composite [Scaled diffuse Lambertian, Scaled specular (Blinn shininess)]: sum from 0 in list order
+YD V3 blinn_phong_at(V3 diffuse, V3 specular, float shininess, const Frame &f, V3 wi, V3 wo) {
+  V3 i = world_to_loc(f, wi), o = world_to_loc(f, wo);
+  V3 acc = vof(0.0f);
+  acc = acc + diffuse * loc_lambertian(i, o);
+  acc = acc + specular * loc_blinn(shininess, i, o);
+  return acc;
+}
+
+// ---- Cameras.hs:40-44,83-86 -------------------------------------------------------------------------
+YD V3 transform_point(const float *m, V3 p) {       // (tf !* V4 x y z 1), normalizePoint = (1/w) *^
+  float tv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float acc = 0.0f;
+    acc = acc + m[i * 4 + 0] * p.x;
+    acc = acc + m[i * 4 + 1] * p.y;
+    acc = acc + m[i * 4 + 2] * p.z;
+    acc = acc + m[i * 4 + 3] * 1.0f;
+    tv[i] = acc;
+  }
+  float iw = 1.0f / tv[3];
+  return v3(iw * tv[0], iw * tv[1], iw * tv[2]);
+}
+
+// ---- sampler (build extension for spp > 1; identical integer hash in oracle/yahr_oracle.c) ----------
+YD unsigned lowbias32(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x;
+}
+YD void sample_offset(int u, int v, int k, int n_strata, unsigned seed, float &du, float &dv) {
+  int i = (n_strata > 1) ? (k % n_strata) : 0, j = (n_strata > 1) ? ((k / n_strata) % n_strata) : 0;
+  unsigned h = lowbias32((unsigned)u + lowbias32((unsigned)v + lowbias32((unsigned)k + lowbias32(seed))));
+  unsigned h2 = lowbias32(h ^ 0x68bc21ebU);
+  float xi1 = (float)(h >> 8) * (1.0f / 16777216.0f);
+  float xi2 = (float)(h2 >> 8) * (1.0f / 16777216.0f);
+  du = ((float)i + xi1) / (float)n_strata;
+  dv = ((float)j + xi2) / (float)n_strata;
+}
+
+}  // namespace yd

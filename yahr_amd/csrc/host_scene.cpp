@@ -1,0 +1,313 @@
+// host_scene.cpp -- expand, collision model, BVH build and flattening (host side, runs once per scene).
+//
+// Restates, array-based and with identical split decisions:
+//   Scene.hs:61-86    expand (TriangleMesh, Subsampled)
+//   main.hs:41-60     buildCollisionModel (primitive order = `objects >>= expand`, material map)
+//   Cameras.hs:58-81  cameraToWorld, rasterToCamera, vtf
+//   Culling.hs:21-112 cull / bvh / buildTree / multiLeaf / midpointSplit / sahSplit
+//   AABBs.hs:10-27,45-53 box algebra;  Shapes.hs:32-33,62-63 primitive bounds
+// and emits the tree in the reference's DFS order as a skip-linked node array (include/yahr_hip.h).
+#include "host_scene.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <limits>
+#include <map>
+#include <numeric>
+#include <stdexcept>
+
+namespace yahr {
+
+namespace {
+
+// ---- Vectors.hs (host copies; same operation order as the device code) ----
+inline Vec3 v3(float x, float y, float z) { Vec3 r; r.x = x; r.y = y; r.z = z; return r; }
+inline Vec3 add(Vec3 a, Vec3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+inline Vec3 sub(Vec3 a, Vec3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline Vec3 neg(Vec3 a) { return v3(-a.x, -a.y, -a.z); }
+inline float dot(Vec3 a, Vec3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }     // Vectors.hs:33
+inline Vec3 scale(float f, Vec3 v) { return v3(f * v.x, f * v.y, f * v.z); }           // (@*) :42-43
+inline Vec3 norm(Vec3 v) { return scale(1.0f / std::sqrt(dot(v, v)), v); }             // :46-47
+inline Vec3 cross(Vec3 a, Vec3 b) {                                                     // :49-53
+  return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+inline float dim(int d, Vec3 v) { return d == 0 ? v.x : (d == 1 ? v.y : v.z); }
+// Haskell class-default min/max (NaN-asymmetric)
+inline float hmin(float x, float y) { return (x <= y) ? x : y; }
+inline float hmax(float x, float y) { return (x <= y) ? y : x; }
+
+struct Box { Vec3 lo, hi; };
+const float kInf = std::numeric_limits<float>::infinity();
+inline Box box_empty() { Box b; b.lo = v3(kInf, kInf, kInf); b.hi = v3(-kInf, -kInf, -kInf); return b; }   // AABBs.hs:10-11
+inline Box box_from_points(Vec3 x, Vec3 y) {                                                               // :13-14
+  Box b; b.lo = v3(hmin(x.x, y.x), hmin(x.y, y.y), hmin(x.z, y.z)); b.hi = v3(hmax(x.x, y.x), hmax(x.y, y.y), hmax(x.z, y.z)); return b;
+}
+inline Box box_include(Box b, Vec3 x) {                                                                    // :16-18
+  Box r; r.lo = v3(hmin(b.lo.x, x.x), hmin(b.lo.y, x.y), hmin(b.lo.z, x.z)); r.hi = v3(hmax(b.hi.x, x.x), hmax(b.hi.y, x.y), hmax(b.hi.z, x.z)); return r;
+}
+inline Box box_join(Box a, Box b) {                                                                        // :25-27
+  Box r; r.lo = v3(hmin(a.lo.x, b.lo.x), hmin(a.lo.y, b.lo.y), hmin(a.lo.z, b.lo.z));
+  r.hi = v3(hmax(a.hi.x, b.hi.x), hmax(a.hi.y, b.hi.y), hmax(a.hi.z, b.hi.z)); return r;
+}
+inline Vec3 box_centroid(Box b) { return add(scale(0.5f, b.lo), scale(0.5f, b.hi)); }                      // :48-49
+inline float box_surf(Box b) { Vec3 d = sub(b.hi, b.lo); return 2.0f * ((d.x * d.y + d.x * d.z) + d.y * d.z); }  // :51-53
+inline int max_dimension(Vec3 v) { if (v.x > v.y && v.x > v.z) return 0; if (v.y > v.z) return 1; return 2; }   // Vectors.hs:62-66
+
+// ---- BVH builder -------------------------------------------------------------------------------
+struct Builder {
+  const std::vector<Box> &boxes;        // per primitive (expand order)
+  std::vector<Vec3> cent;               // centroid of each primitive's box
+  std::vector<int32_t> order;           // permutation; after the build it is the leaf order
+  std::vector<int32_t> scratch;
+  std::vector<yahr_node> &nodes;
+  int split_mode;
+
+  Builder(const std::vector<Box> &b, std::vector<yahr_node> &n, int split) : boxes(b), nodes(n), split_mode(split) {
+    cent.resize(b.size());
+    for (size_t i = 0; i < b.size(); ++i) cent[i] = box_centroid(b[i]);
+    order.resize(b.size()); std::iota(order.begin(), order.end(), 0);
+    scratch.resize(b.size());
+  }
+
+  static void put(yahr_node &nd, Box bb, int32_t a, int32_t b) {
+    nd.lo[0] = bb.lo.x; nd.lo[1] = bb.lo.y; nd.lo[2] = bb.lo.z; nd.a = a;
+    nd.hi[0] = bb.hi.x; nd.hi[1] = bb.hi.y; nd.hi[2] = bb.hi.z; nd.b = b;
+  }
+
+  Box emit_multi_leaf(int32_t first, int32_t n) {                    // Culling.hs:52-54
+    Box bb = box_empty();
+    for (int32_t i = 0; i < n; ++i) bb = box_join(bb, boxes[order[first + i]]);
+    yahr_node nd; put(nd, bb, n, first); nodes.push_back(nd);
+    return bb;
+  }
+
+  // stable partition of order[first, first+n) by pred; returns size of the left part
+  template <class P> int32_t stable_split(int32_t first, int32_t n, P pred) {
+    int32_t nl = 0, nr = 0;
+    for (int32_t i = 0; i < n; ++i) {
+      int32_t p = order[first + i];
+      if (pred(p)) order[first + nl++] = p; else scratch[first + nr++] = p;
+    }
+    std::copy(scratch.begin() + first, scratch.begin() + first + nr, order.begin() + first + nl);
+    return nl;
+  }
+
+  int bucket_id(int32_t p, int d, float cmin, float cmax) const {   // Culling.hs:69-79
+    float length = cmax - cmin;
+    float dd = dim(d, cent[p]) - cmin;
+    float frac = dd / length;
+    float v = 16.0f * frac;
+    // GHC floor :: Float -> Int of NaN/inf = minBound, then `max 0` -> 0
+    long fl = (std::isnan(v) || std::isinf(v)) ? -1L : (long)std::floor(v);
+    if (fl < 0) fl = 0;
+    if (fl > 15) fl = 15;
+    return (int)fl;
+  }
+
+  int32_t midpoint(int32_t first, int32_t n, int d, Box cb) {       // Culling.hs:56-60
+    float mid = dim(d, box_centroid(cb));
+    return stable_split(first, n, [&](int32_t p) { return dim(d, cent[p]) <= mid; });
+  }
+
+  int32_t sah(int32_t first, int32_t n, int d, Box cb) {            // Culling.hs:62-112
+    if (!(n > 4)) return midpoint(first, n, d, cb);
+    constexpr int NB = 16;
+    float cmin = dim(d, cb.lo), cmax = dim(d, cb.hi);
+    int cnt[NB]; Box bbs[NB];
+    for (int i = 0; i < NB; ++i) { cnt[i] = 0; bbs[i] = box_empty(); }
+    for (int32_t i = 0; i < n; ++i) {
+      int32_t p = order[first + i];
+      int b = bucket_id(p, d, cmin, cmax);
+      cnt[b] += 1; bbs[b] = box_join(bbs[b], boxes[p]);
+    }
+    float wrapped = 0.0f;
+    for (int i = 0; i < NB; ++i) wrapped = wrapped + box_surf(bbs[i]);
+    int best_i = 0; float best_c = 0.0f;
+    for (int i = 0; i <= NB - 2; ++i) {
+      Box b0 = box_empty(), b1 = box_empty(); int c0 = 0, c1 = 0;
+      for (int k = 0; k <= i; ++k) { b0 = box_join(b0, bbs[k]); c0 += cnt[k]; }
+      for (int k = i + 1; k < NB; ++k) { b1 = box_join(b1, bbs[k]); c1 += cnt[k]; }
+      float cost = 0.125f + ((float)c0 * box_surf(b0) + (float)c1 * box_surf(b1)) / wrapped;
+      // minimumBy (compare `on` snd): keep x unless compare x y == GT; compare is GT when x>y or unordered
+      if (i == 0) { best_i = 0; best_c = cost; }
+      else if (!(best_c < cost) && !(best_c == cost)) { best_i = i; best_c = cost; }
+    }
+    return stable_split(first, n, [&](int32_t p) { return bucket_id(p, d, cmin, cmax) <= best_i; });
+  }
+
+  // buildTree (Culling.hs:31-50); emits nodes in DFS order and returns the subtree's box
+  Box build(int max_depth, int32_t first, int32_t n) {
+    if (n == 0) {                                                    // :32  (empty, nullCollider)
+      yahr_node nd; put(nd, box_empty(), 0, first); nodes.push_back(nd);
+      return box_empty();
+    }
+    if (n == 1) {                                                    // :33
+      Box bb = boxes[order[first]];
+      yahr_node nd; put(nd, bb, 1, first); nodes.push_back(nd);
+      return bb;
+    }
+    if (max_depth == 0) return emit_multi_leaf(first, n);            // :34
+    // bbOfCentroids = boundAllPoints (map centroid bbs)  (:49, AABBs.hs:20-23)
+    Box cb = box_from_points(cent[order[first]], cent[order[first + 1]]);
+    for (int32_t i = 2; i < n; ++i) cb = box_include(cb, cent[order[first + i]]);
+    int d = max_dimension(sub(cb.hi, cb.lo));                        // :48
+    int32_t nl = (split_mode == YAHR_SPLIT_SAH) ? sah(first, n, d, cb) : midpoint(first, n, d, cb);
+    if (nl == n) return emit_multi_leaf(first, n);                   // :36-37  null xs2
+    size_t me = nodes.size();
+    nodes.push_back(yahr_node{});
+    Box b1 = build(max_depth - 1, first, nl);
+    Box b2 = build(max_depth - 1, first + nl, n - nl);
+    Box jb = box_join(b1, b2);                                       // :39
+    put(nodes[me], jb, (int32_t)nodes.size(), -1);
+    return jb;
+  }
+};
+
+void m44_mul(const float f[16], const float g[16], float out[16]) {   // Linear (!*!): foldl' (^+^) zero
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      float acc = 0.0f;
+      for (int k = 0; k < 4; ++k) acc = acc + f[i * 4 + k] * g[k * 4 + j];
+      out[i * 4 + j] = acc;
+    }
+}
+
+void put3(float d[3], Vec3 v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; }
+
+}  // namespace
+
+void camera_matrices(const Camera &c, float tf[16], float vtf[16]) {
+  Vec3 forward = norm(c.look);                                       // Cameras.hs:59-65
+  Vec3 left = norm(cross(forward, c.up));
+  Vec3 up = cross(left, forward);
+  Vec3 a = neg(left), b = up, cc = forward;
+  float dir_tf[16] = {a.x, b.x, cc.x, 0, a.y, b.y, cc.y, 0, a.z, b.z, cc.z, 0, 0, 0, 0, 1};
+  float tr[16] = {1, 0, 0, c.pos.x, 0, 1, 0, c.pos.y, 0, 0, 1, c.pos.z, 0, 0, 0, 1};
+  m44_mul(tr, dir_tf, tf);
+  float frame_w = c.imW / c.imH, frame_h = 1.0f;                     // :68-75
+  float r2c[16] = {frame_w / c.imW, 0, 0, -(frame_w / 2.0f),
+                   0, -(frame_h / c.imH), 0, frame_h / 2.0f,
+                   0, 0, 1, 0,
+                   0, 0, 0, 1};
+  m44_mul(tf, r2c, vtf);                                             // :81
+}
+
+void expand_object(const SceneObject &o, const std::function<int32_t(const std::string &)> &mat_of,
+                   std::vector<Primitive> &out) {
+  switch (o.kind) {
+    case SceneObject::TriangleMesh: {                                // Scene.hs:62-79
+      size_t n = o.tris.size() / 3;
+      if (o.has_smooth && o.smooth.size() < n) n = o.smooth.size();  // zipWith truncates
+      int32_t mat = mat_of(o.material_id);
+      for (size_t k = 0; k < n; ++k) {
+        int32_t i0 = o.tris[3 * k], i1 = o.tris[3 * k + 1], i2 = o.tris[3 * k + 2];
+        auto chk = [&](int32_t i, size_t lim, const char *what) {
+          if (i < 0 || (size_t)i >= lim) throw std::runtime_error(std::string("TriangleMesh index out of bounds (") + what + ")");
+        };
+        chk(i0, o.points.size(), "points"); chk(i1, o.points.size(), "points"); chk(i2, o.points.size(), "points");
+        Primitive t; t.kind = 0; t.mat = mat;
+        t.p0 = o.points[i0]; t.p1 = o.points[i1]; t.p2 = o.points[i2];
+        bool sm = o.has_smooth ? (o.smooth[k] != 0) : false;        // fromMaybe (repeat False)
+        if (o.has_normals && sm) {
+          chk(i0, o.normals.size(), "normals"); chk(i1, o.normals.size(), "normals"); chk(i2, o.normals.size(), "normals");
+          t.n0 = o.normals[i0]; t.n1 = o.normals[i1]; t.n2 = o.normals[i2];
+        } else {
+          Vec3 nf = norm(cross(sub(t.p2, t.p0), sub(t.p1, t.p0)));   // :78
+          t.n0 = nf; t.n1 = nf; t.n2 = nf;
+        }
+        out.push_back(t);
+      }
+      break;
+    }
+    case SceneObject::Subsampled: {                                  // Scene.hs:80-85
+      std::vector<Primitive> all;
+      for (const auto &c : o.children) expand_object(c, mat_of, all);
+      long of_hundred = (long)std::ceil(o.subsample_size * 100.0f);
+      size_t pos = 0, n = all.size();
+      while (pos < n) {
+        long take = of_hundred < 0 ? 0 : of_hundred;
+        for (long i = 0; i < take && pos + (size_t)i < n; ++i) out.push_back(all[pos + (size_t)i]);
+        pos += (size_t)take; if (pos > n) pos = n;
+        long drop = 100 - of_hundred; if (drop < 0) drop = 0;
+        if (take == 0 && drop == 0) break;
+        pos += (size_t)drop;
+      }
+      break;
+    }
+    case SceneObject::Sphere: {                                      // :86  expand x = [x]
+      Primitive p; p.kind = 1; p.p0 = o.position; p.radius = o.radius; p.mat = mat_of(o.material_id);
+      out.push_back(p); break;
+    }
+    case SceneObject::Triangle: {
+      Primitive p; p.kind = 0; p.p0 = o.p0; p.p1 = o.p1; p.p2 = o.p2; p.n0 = o.n0; p.n1 = o.n1; p.n2 = o.n2;
+      p.mat = mat_of(o.material_id);
+      out.push_back(p); break;
+    }
+  }
+}
+
+void HostScene::build() {
+  if (built) return;
+  // materials: Data.Map.fromList -- the later duplicate wins (main.hs:57)
+  std::map<std::string, int32_t> mat_index;
+  mat_recs.clear();
+  for (const auto &m : materials) {
+    yahr_material r{}; put3(r.diffuse, m.diffuse); put3(r.specular, m.specular); r.shininess = m.shininess;
+    mat_index[m.id] = (int32_t)mat_recs.size();
+    mat_recs.push_back(r);
+  }
+  light_recs.clear();
+  for (const auto &l : lights) { yahr_light r{}; put3(r.pos, l.pos); put3(r.spectrum, l.spectrum); light_recs.push_back(r); }
+
+  // sceneObjects = S.objects s >>= S.expand   (main.hs:44); unknown material id: error when first
+  // shaded (Map.!, main.hs:55) -> index -1, reported by the render call as YAHR_E_MATERIAL
+  auto mat_of = [&](const std::string &id) -> int32_t {
+    auto it = mat_index.find(id);
+    return it == mat_index.end() ? -1 : it->second;
+  };
+  prims.clear();
+  for (const auto &o : objects) expand_object(o, mat_of, prims);
+  std::vector<Box> boxes; boxes.reserve(prims.size());
+  for (const auto &p : prims) {
+    if (p.kind == 1) {
+      Vec3 r3 = v3(p.radius, p.radius, p.radius);
+      boxes.push_back(box_from_points(add(p.p0, r3), sub(p.p0, r3)));                       // Shapes.hs:32-33
+    } else {
+      boxes.push_back(box_include(box_from_points(p.p0, p.p1), p.p2));                      // Shapes.hs:62-63
+    }
+  }
+
+  nodes.clear();
+  Builder bld(boxes, nodes, split);
+  if (!prims.empty()) bld.build(bvh_depth, 0, (int32_t)prims.size());     // bvh _ _ [] = const Nothing (Culling.hs:28)
+
+  prim_recs.resize(prims.size()); prim_normals.resize(prims.size());
+  for (size_t i = 0; i < prims.size(); ++i) {
+    const Primitive &p = prims[bld.order[i]];
+    yahr_prim r{}; yahr_prim_normals nr{};
+    r.mat = p.mat; r.kind = p.kind; r.orig = bld.order[i];
+    put3(r.p0, p.p0);
+    if (p.kind == 1) { r.e1[0] = p.radius; }
+    else {
+      put3(r.e1, sub(p.p1, p.p0)); put3(r.e2, sub(p.p2, p.p0));     // e1, e2 of Shapes.hs:38-39
+      put3(nr.n0, p.n0); put3(nr.n1, p.n1); put3(nr.n2, p.n2);
+    }
+    prim_recs[i] = r; prim_normals[i] = nr;
+  }
+
+  std::memset(&flat, 0, sizeof flat);
+  flat.abi_version = YAHR_ABI_VERSION;
+  flat.width = (int32_t)std::floor(camera.imW); flat.height = (int32_t)std::floor(camera.imH);   // main.hs:122-123
+  flat.depth = depth;
+  camera_matrices(camera, flat.cam_tf, flat.cam_vtf);
+  flat.focal = camera.focal;
+  flat.n_nodes = (int32_t)nodes.size(); flat.nodes = nodes.data();
+  flat.n_prims = (int32_t)prim_recs.size(); flat.prims = prim_recs.data(); flat.normals = prim_normals.data();
+  flat.n_mats = (int32_t)mat_recs.size(); flat.mats = mat_recs.data();
+  flat.n_lights = (int32_t)light_recs.size(); flat.lights = light_recs.data();
+  built = true;
+}
+
+}  // namespace yahr

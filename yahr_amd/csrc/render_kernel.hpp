@@ -1,0 +1,45 @@
+// render_kernel.hpp -- kernel argument blocks and launchers shared by render_kernel.hip and abi_device.cpp
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+// device view of a yahr_scene (include/yahr_hip.h); every record array is read as float4 words
+struct DScene {
+  const float4 *nodes;     // 2 per yahr_node
+  const float4 *prims;     // 3 per yahr_prim
+  const float4 *normals;   // 3 per yahr_prim_normals
+  const float4 *mats;      // 2 per yahr_material
+  const float4 *lights;    // 2 per yahr_light
+  int n_nodes, n_prims, n_mats, n_lights;
+  int depth;
+  float origin[3];         // transformPoint tf (Vec3 0 0 0)   (Cameras.hs:84)
+  float vtf[16];           // Cameras.hs:81
+  float focal;
+};
+
+struct RParams {
+  int width, height;       // full image
+  int n_local_rows;        // rows this launch renders (compacted)
+  int row0;                // first global row of strip 0 of this shard
+  int strip_rows, n_shards;
+  int tiles_x, n_tiles;
+  int spp, n_strata; unsigned seed;
+  int tile_mode;           // 0: 8x8 wave tiles, 1: reference squareBatches windows
+  int xcd_swizzle;
+  const int4 *windows;     // tile_mode 1: {x0,y0,x1,y1} per batch
+};
+
+enum { TRAV_LANE = 1, TRAV_PACKET = 2, TRAV_HYBRID = 3 };
+
+enum { CTR_PRIMARY = 0, CTR_REFLECTION, CTR_SHADOW, CTR_SHADED, CTR_BAD_MAT,
+       CTR_BOX, CTR_TRI, CTR_SPH, CTR_WAVE_NODES, CTR_WAVE_PRIMS, CTR_COUNT };
+
+namespace yahr_dev {
+hipError_t launch_render(const DScene &sc, const RParams &rp, int mode, int n_blocks, float *out,
+                         unsigned long long *ctr, bool stats, hipStream_t st);
+hipError_t launch_trace(const DScene &sc, int mode, int n, const float *rays, int any_hit, int *prim_out,
+                        float *t_out, hipStream_t st);
+hipError_t launch_radiance(const DScene &sc, int mode, int n, const float *rays, float *rgb,
+                           unsigned long long *ctr, hipStream_t st);
+hipError_t launch_camera_rays(const DScene &sc, int n, const float *uv, float *rays, hipStream_t st);
+}  // namespace yahr_dev

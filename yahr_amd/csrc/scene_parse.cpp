@@ -1,0 +1,415 @@
+// scene_parse.cpp -- loader for the .yahrr scene text format.
+//
+// The format is whatever GHC's *derived* `Read` instance accepts for `Scene` (Scene.hs:42,50,58;
+// Vectors.hs:6; Cameras.hs:56; Culling.hs:18-19; Integrators.hs:20; Lights.hs:7), as used by
+// `read sceneFile :: S.Scene` (main.hs:117).  This is a recursive-descent restatement of that grammar:
+//   * Haskell lexing: free whitespace, identifiers, numeric and string literals, ( ) [ ] { } , =
+//   * any value may be wrapped in redundant parentheses; a constructor applied to arguments needs them
+//     when it is itself an argument (precedence 11), a record or nullary constructor does not
+//   * record syntax needs every field, in declaration order
+//   * a leading '-' is accepted before a numeric literal at any precedence (GHC.Read.readNumber), which
+//     is why `Vec3 0.4 -0.3 1` (scene.yahrr:6) and `(Vec3 -1000.000000 ...)` (compat/yahr.py:142) parse
+//   * integer literals are accepted for Float fields; Int fields take integer literals only
+// `lenient` additionally accepts the stale dialect of the bundled scene.yahrr (SURVEY finding 2).
+#include <cerrno>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <limits>
+
+#include "host_scene.hpp"
+
+namespace yahr {
+namespace {
+
+enum class Tok { End, Ident, Number, String, Punct };
+
+struct Token {
+  Tok kind = Tok::End;
+  size_t pos = 0, len = 0;
+  char punct = 0;
+  bool integral = false;      // Number: no fraction and no exponent
+  std::string str;            // String: decoded
+};
+
+class Parser {
+ public:
+  Parser(const char *t, size_t n, bool lenient) : text_(t), n_(n), lenient_(lenient) {}
+
+  std::unique_ptr<HostScene> scene() {
+    auto hs = std::make_unique<HostScene>();
+    parens(0, 11, [&] {
+      expect_ident("Scene"); expect('{');
+      field("integrator"); hs->depth = integrator(0); expect(',');
+      field("cullingMode"); culling(0, *hs); expect(',');
+      field("camera"); hs->camera = camera(0); expect(',');
+      field("materials"); list([&] { hs->materials.push_back(material(0)); }); expect(',');
+      field("lights"); list([&] { hs->lights.push_back(light(0)); }); expect(',');
+      field("objects"); list([&] { hs->objects.push_back(object(0)); });
+      expect('}');
+    });
+    if (peek().kind != Tok::End) fail("trailing input after Scene");   // `read` requires a full parse
+    return hs;
+  }
+
+ private:
+  const char *text_; size_t n_; bool lenient_;
+  size_t pos_ = 0;
+  bool has_peek_ = false; Token peek_; size_t after_peek_ = 0;
+
+  [[noreturn]] void fail(const std::string &m) { throw ParseError{m, pos_}; }
+
+  static bool ident_start(char c) { return (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || c == '_'; }
+  static bool ident_char(char c) { return ident_start(c) || (c >= '0' && c <= '9') || c == '\''; }
+  static bool digit(char c) { return c >= '0' && c <= '9'; }
+
+  Token lex(size_t &p) {
+    while (p < n_ && (text_[p] == ' ' || text_[p] == '\n' || text_[p] == '\t' || text_[p] == '\r' ||
+                      text_[p] == '\f' || text_[p] == '\v'))
+      ++p;
+    Token t; t.pos = p;
+    if (p >= n_) { t.kind = Tok::End; return t; }
+    char c = text_[p];
+    if (ident_start(c)) {
+      size_t q = p + 1;
+      while (q < n_ && ident_char(text_[q])) ++q;
+      t.kind = Tok::Ident; t.len = q - p; p = q; return t;
+    }
+    if (digit(c)) {
+      size_t q = p; t.integral = true;
+      if (c == '0' && q + 2 < n_ + 0 && (text_[q + 1] == 'x' || text_[q + 1] == 'X' || text_[q + 1] == 'o' ||
+                                         text_[q + 1] == 'O') && q + 2 < n_ && std::isxdigit((unsigned char)text_[q + 2])) {
+        q += 2;
+        while (q < n_ && std::isxdigit((unsigned char)text_[q])) ++q;
+      } else {
+        while (q < n_ && digit(text_[q])) ++q;
+        if (q + 1 < n_ && text_[q] == '.' && digit(text_[q + 1])) {   // "5." is not a fractional literal
+          t.integral = false; ++q;
+          while (q < n_ && digit(text_[q])) ++q;
+        }
+        if (q < n_ && (text_[q] == 'e' || text_[q] == 'E')) {
+          size_t r = q + 1;
+          if (r < n_ && (text_[r] == '+' || text_[r] == '-')) ++r;
+          if (r < n_ && digit(text_[r])) {
+            t.integral = false;
+            while (r < n_ && digit(text_[r])) ++r;
+            q = r;
+          }
+        }
+      }
+      t.kind = Tok::Number; t.len = q - p; p = q; return t;
+    }
+    if (c == '"') {
+      size_t q = p + 1; t.kind = Tok::String;
+      while (true) {
+        if (q >= n_) { pos_ = p; fail("unterminated string literal"); }
+        char d = text_[q];
+        if (d == '"') { ++q; break; }
+        if (d == '\n') { pos_ = q; fail("newline in string literal"); }
+        if (d != '\\') { t.str.push_back(d); ++q; continue; }
+        ++q;
+        if (q >= n_) { pos_ = q; fail("bad escape"); }
+        char e = text_[q];
+        switch (e) {
+          case '\\': t.str.push_back('\\'); ++q; break;
+          case '"': t.str.push_back('"'); ++q; break;
+          case '\'': t.str.push_back('\''); ++q; break;
+          case 'n': t.str.push_back('\n'); ++q; break;
+          case 't': t.str.push_back('\t'); ++q; break;
+          case 'r': t.str.push_back('\r'); ++q; break;
+          case 'a': t.str.push_back('\a'); ++q; break;
+          case 'b': t.str.push_back('\b'); ++q; break;
+          case 'f': t.str.push_back('\f'); ++q; break;
+          case 'v': t.str.push_back('\v'); ++q; break;
+          case '&': ++q; break;                                  // empty escape
+          default:
+            if (digit(e)) {                                      // \DDD decimal code point (ASCII subset)
+              unsigned v = 0;
+              while (q < n_ && digit(text_[q])) { v = v * 10 + (unsigned)(text_[q] - '0'); ++q; }
+              if (v > 0x10FFFF) { pos_ = q; fail("bad numeric escape"); }
+              append_utf8(t.str, v);
+            } else if (e == 'x' && q + 1 < n_ && std::isxdigit((unsigned char)text_[q + 1])) {
+              ++q; unsigned v = 0;
+              while (q < n_ && std::isxdigit((unsigned char)text_[q])) {
+                char h = text_[q]; v = v * 16 + (unsigned)(digit(h) ? h - '0' : (std::tolower(h) - 'a' + 10)); ++q;
+              }
+              append_utf8(t.str, v);
+            } else if (e == ' ' || e == '\n' || e == '\t' || e == '\r') {   // string gap \  ...  \ //
+              while (q < n_ && (text_[q] == ' ' || text_[q] == '\n' || text_[q] == '\t' || text_[q] == '\r')) ++q;
+              if (q >= n_ || text_[q] != '\\') { pos_ = q; fail("bad string gap"); }
+              ++q;
+            } else { pos_ = q; fail("unsupported string escape"); }
+        }
+      }
+      t.len = q - p; p = q; return t;
+    }
+    if (std::strchr("{}[](),=-", c)) { t.kind = Tok::Punct; t.punct = c; t.len = 1; ++p; return t; }
+    pos_ = p; fail(std::string("unexpected character '") + c + "'");
+  }
+
+  static void append_utf8(std::string &s, unsigned v) {
+    if (v < 0x80) s.push_back((char)v);
+    else if (v < 0x800) { s.push_back((char)(0xC0 | (v >> 6))); s.push_back((char)(0x80 | (v & 0x3F))); }
+    else if (v < 0x10000) { s.push_back((char)(0xE0 | (v >> 12))); s.push_back((char)(0x80 | ((v >> 6) & 0x3F))); s.push_back((char)(0x80 | (v & 0x3F))); }
+    else { s.push_back((char)(0xF0 | (v >> 18))); s.push_back((char)(0x80 | ((v >> 12) & 0x3F))); s.push_back((char)(0x80 | ((v >> 6) & 0x3F))); s.push_back((char)(0x80 | (v & 0x3F))); }
+  }
+
+  const Token &peek() {
+    if (!has_peek_) { size_t p = pos_; peek_ = lex(p); after_peek_ = p; has_peek_ = true; }
+    return peek_;
+  }
+  Token next() { peek(); Token t = std::move(peek_); pos_ = after_peek_; has_peek_ = false; return t; }
+  size_t mark() const { return pos_; }
+  void reset(size_t m) { pos_ = m; has_peek_ = false; }
+
+  bool is_punct(char c) { const Token &t = peek(); return t.kind == Tok::Punct && t.punct == c; }
+  bool is_ident(const char *s) {
+    const Token &t = peek();
+    return t.kind == Tok::Ident && t.len == std::strlen(s) && std::memcmp(text_ + t.pos, s, t.len) == 0;
+  }
+  void expect(char c) {
+    if (!is_punct(c)) fail(std::string("expected '") + c + "'");
+    next();
+  }
+  void expect_ident(const char *s) {
+    if (!is_ident(s)) fail(std::string("expected ") + s);
+    next();
+  }
+  void field(const char *name) { expect_ident(name); expect('='); }
+
+  // GHC.Read `parens` + `prec`: optional redundant parentheses; outside them the body needs
+  // current precedence <= body_prec (10 = constructor application, 11 = record/atom).
+  template <class F> void parens(int prec, int body_prec, F body) {
+    if (is_punct('(')) { next(); parens(0, body_prec, body); expect(')'); return; }
+    if (prec > body_prec) fail("constructor application needs parentheses here");
+    body();
+  }
+
+  template <class F> void list(F elem) {          // GHC.Read.list, elements at precedence 0
+    parens(0, 11, [&] {
+      expect('[');
+      if (is_punct(']')) { next(); return; }
+      while (true) {
+        elem();
+        if (is_punct(',')) { next(); continue; }
+        expect(']'); break;
+      }
+    });
+  }
+
+  // readNumber: optional parens, optional '-', then a numeric lexeme (or NaN / Infinity for Float)
+  float number_f() {
+    float out = 0;
+    parens(0, 11, [&] {
+      bool neg = false;
+      if (is_punct('-')) { next(); neg = true; }
+      Token t = next();
+      float v;
+      if (t.kind == Tok::Number) {
+        std::string s(text_ + t.pos, t.len);
+        if (s.size() > 2 && s[0] == '0' && (s[1] == 'o' || s[1] == 'O')) v = (float)std::strtoull(s.c_str() + 2, nullptr, 8);
+        else v = std::strtof(s.c_str(), nullptr);              // correctly rounded, like fromRational
+      } else if (t.kind == Tok::Ident && t.len == 3 && !std::memcmp(text_ + t.pos, "NaN", 3)) {
+        v = std::numeric_limits<float>::quiet_NaN();
+      } else if (t.kind == Tok::Ident && t.len == 8 && !std::memcmp(text_ + t.pos, "Infinity", 8)) {
+        v = std::numeric_limits<float>::infinity();
+      } else { pos_ = t.pos; fail("expected a number"); }
+      out = neg ? -v : v;
+    });
+    return out;
+  }
+  int32_t number_i() {
+    int32_t out = 0;
+    parens(0, 11, [&] {
+      bool neg = false;
+      if (is_punct('-')) { next(); neg = true; }
+      Token t = next();
+      if (t.kind != Tok::Number || !t.integral) { pos_ = t.pos; fail("expected an integer"); }
+      std::string s(text_ + t.pos, t.len);
+      long long v;
+      if (s.size() > 2 && s[0] == '0' && (s[1] == 'o' || s[1] == 'O')) v = std::strtoll(s.c_str() + 2, nullptr, 8);
+      else v = std::strtoll(s.c_str(), nullptr, 0);
+      out = (int32_t)(neg ? -v : v);
+    });
+    return out;
+  }
+  std::string string_lit() {
+    std::string out;
+    parens(0, 11, [&] {
+      Token t = next();
+      if (t.kind != Tok::String) { pos_ = t.pos; fail("expected a string literal"); }
+      out = std::move(t.str);
+    });
+    return out;
+  }
+  bool boolean() {
+    bool out = false;
+    parens(0, 11, [&] {
+      if (is_ident("True")) { next(); out = true; }
+      else if (is_ident("False")) { next(); out = false; }
+      else fail("expected True or False");
+    });
+    return out;
+  }
+
+  Vec3 vec3(int prec) {                             // data Vec3 = Vec3 !Float !Float !Float  (Vectors.hs:5)
+    Vec3 v;
+    parens(prec, 10, [&] {
+      expect_ident("Vec3");
+      v.x = number_f(); v.y = number_f(); v.z = number_f();
+    });
+    return v;
+  }
+
+  int integrator(int prec) {                        // Integrators.hs:18-20
+    int d = 0;
+    parens(prec, 11, [&] {
+      expect_ident("WhittedIntegrator"); expect('{');
+      field("recursionDepth"); d = number_i();
+      expect('}');
+    });
+    return d;
+  }
+
+  void culling(int prec, HostScene &hs) {           // Culling.hs:18-19
+    parens(prec, 10, [&] {
+      expect_ident("BVH");
+      hs.bvh_depth = number_i();
+      parens(11, 11, [&] {
+        if (is_ident("Midpoint")) { next(); hs.split = YAHR_SPLIT_MIDPOINT; }
+        else if (is_ident("SurfaceAreaHeuristic")) { next(); hs.split = YAHR_SPLIT_SAH; }
+        else fail("expected Midpoint or SurfaceAreaHeuristic");
+      });
+    });
+  }
+
+  Camera camera(int prec) {                         // Cameras.hs:54-56
+    Camera c;
+    parens(prec, 11, [&] {
+      expect_ident("Camera"); expect('{');
+      field("imW"); c.imW = number_f(); expect(',');
+      field("imH"); c.imH = number_f(); expect(',');
+      field("focalLength"); c.focal = number_f(); expect(',');
+      field("lookDir"); c.look = vec3(0); expect(',');
+      field("upDir"); c.up = vec3(0); expect(',');
+      field("position"); c.pos = vec3(0);
+      expect('}');
+    });
+    return c;
+  }
+
+  Material material(int prec) {                     // Scene.hs:45-50
+    Material m;
+    parens(prec, 11, [&] {
+      expect_ident("BlinnPhongMaterial"); expect('{');
+      field("id"); m.id = string_lit(); expect(',');
+      field("ambient"); m.ambient = vec3(0); expect(',');
+      field("diffuse"); m.diffuse = vec3(0); expect(',');
+      field("specular"); m.specular = vec3(0); expect(',');
+      field("shininess"); m.shininess = number_f();
+      expect('}');
+    });
+    return m;
+  }
+
+  Light light(int prec) {                           // Lights.hs:7
+    Light l;
+    parens(prec, 10, [&] {
+      expect_ident("PointLight");
+      l.pos = vec3(11);
+      bool one_arg = is_punct(',') || is_punct(']') || is_punct(')');
+      if (one_arg && lenient_) {
+        // stale dialect (scene.yahrr:34): no spectrum.  The value the old code used is unknown; (100,100,100)
+        // is this build's documented guess (DESIGN.md "scene.yahrr repair").
+        l.spectrum = Vec3{100.f, 100.f, 100.f};
+      } else {
+        l.spectrum = vec3(11);
+      }
+    });
+    return l;
+  }
+
+  template <class F> void maybe(F just) {           // Maybe a: Nothing | Just a (argument at precedence 11)
+    bool done = false;
+    // `Nothing` is nullary (any precedence); `Just x` is an application (precedence 10) -- field values
+    // are read at precedence 0, so both are legal bare.
+    parens(0, 10, [&] {
+      if (is_ident("Nothing")) { next(); done = true; return; }
+      expect_ident("Just");
+      just();
+    });
+    (void)done;
+  }
+
+  void tri_tuple(std::vector<int32_t> &out) {       // (Int, Int, Int), possibly inside redundant parens
+    size_t m = mark();
+    expect('(');
+    try {
+      int32_t a = number_i(); expect(',');
+      int32_t b = number_i(); expect(',');
+      int32_t c = number_i(); expect(')');
+      out.push_back(a); out.push_back(b); out.push_back(c);
+      return;
+    } catch (const ParseError &) {
+      reset(m);
+    }
+    expect('('); tri_tuple(out); expect(')');       // redundant parentheses around the whole tuple
+  }
+
+  SceneObject object(int prec) {                    // Scene.hs:15-42
+    SceneObject o;
+    parens(prec, 11, [&] {
+      if (is_ident("Sphere")) {
+        next(); expect('{'); o.kind = SceneObject::Sphere;
+        field("position"); o.position = vec3(0); expect(',');
+        field("radius"); o.radius = number_f(); expect(',');
+        field("materialId"); o.material_id = string_lit();
+        expect('}');
+      } else if (is_ident("Triangle")) {
+        next(); expect('{'); o.kind = SceneObject::Triangle;
+        field("p0"); o.p0 = vec3(0); expect(',');
+        field("p1"); o.p1 = vec3(0); expect(',');
+        field("p2"); o.p2 = vec3(0); expect(',');
+        field("n0"); o.n0 = vec3(0); expect(',');
+        field("n1"); o.n1 = vec3(0); expect(',');
+        field("n2"); o.n2 = vec3(0); expect(',');
+        field("materialId"); o.material_id = string_lit();
+        expect('}');
+      } else if (is_ident("TriangleMesh")) {
+        next(); expect('{'); o.kind = SceneObject::TriangleMesh;
+        field("triangleMeshPoints"); list([&] { o.points.push_back(vec3(0)); }); expect(',');
+        if (!lenient_ || is_ident("triangleMeshNormals")) {
+          field("triangleMeshNormals");
+          maybe([&] { o.has_normals = true; parens(11, 11, [&] { list([&] { o.normals.push_back(vec3(0)); }); }); });
+          expect(',');
+        }
+        field("triangleMeshTriangles"); list([&] { tri_tuple(o.tris); }); expect(',');
+        if (!lenient_ || is_ident("triangleMeshSmooth")) {
+          field("triangleMeshSmooth");
+          maybe([&] { o.has_smooth = true; parens(11, 11, [&] { list([&] { o.smooth.push_back(boolean() ? 1 : 0); }); }); });
+          expect(',');
+        }
+        field("materialId"); o.material_id = string_lit();
+        expect('}');
+      } else if (is_ident("Subsampled")) {
+        next(); expect('{'); o.kind = SceneObject::Subsampled;
+        field("subsampleSize"); o.subsample_size = number_f(); expect(',');
+        field("subsampledObjects"); list([&] { o.children.push_back(object(0)); });
+        expect('}');
+      } else {
+        fail("expected Sphere, Triangle, TriangleMesh or Subsampled");
+      }
+    });
+    return o;
+  }
+};
+
+}  // namespace
+
+std::unique_ptr<HostScene> parse_scene(const char *text, size_t len, bool lenient) {
+  Parser p(text, len, lenient);
+  return p.scene();
+}
+
+}  // namespace yahr

@@ -1,0 +1,93 @@
+// yahr_main.cpp -- drop-in command line of the reference executable (main.hs:28-38,112-145):
+//
+//     yahr INPUT OUTPUT [--parallel-mode MODE | -p MODE] [+RTS -N<k> ... [-RTS]]
+//
+// INPUT is a .yahrr scene (derived-Read text), OUTPUT an image (PNG like the reference; .ppm / .pfm by
+// extension).  MODE keeps the reference's values sequential | eval | par (main.hs:134-137) -- they only
+// chose a CPU scheduling strategy there and all select the HIP path here -- plus the explicit `hip`.
+// `+RTS ... -RTS` (appended by the Blender add-on, render_engine.py:44-47) is accepted; -N<k> is echoed
+// in the status line.  Exit status: 0 on success, 1 on any error with the message on stderr, like an
+// uncaught Haskell exception.  Environment: YAHR_DEVICES=<n> limits the GPUs used (default: all),
+// YAHR_LENIENT=1 accepts the stale bundled scene.yahrr dialect, YAHR_SPP=<n> supersampling extension.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/yahr_hip.h"
+
+static int die(const std::string &msg) {
+  std::fprintf(stderr, "yahr: %s\n", msg.c_str());
+  return 1;
+}
+
+static bool ends_with(const std::string &s, const char *suf) {
+  size_t n = std::strlen(suf);
+  return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+
+int main(int argc, char **argv) {
+  std::vector<std::string> pos;
+  std::string mode = "sequential";                       // optFlag "sequential" "parallel-mode" (main.hs:38)
+  int threads = 1;
+  bool in_rts = false;
+  for (int i = 1; i < argc; ++i) {
+    std::string a = argv[i];
+    if (a == "+RTS") { in_rts = true; continue; }
+    if (a == "-RTS") { in_rts = false; continue; }
+    if (in_rts) {
+      if (a.rfind("-N", 0) == 0 && a.size() > 2) threads = std::atoi(a.c_str() + 2);
+      continue;
+    }
+    if (a == "-p" || a == "--parallel-mode") {
+      if (i + 1 >= argc) return die("option " + a + " needs a value");
+      mode = argv[++i]; continue;
+    }
+    if (a.rfind("--parallel-mode=", 0) == 0) { mode = a.substr(16); continue; }
+    if (a == "-h" || a == "--help") {
+      std::printf("usage: yahr input output [-p|--parallel-mode sequential|eval|par|hip] [+RTS -N<k> -RTS]\n");
+      return 0;
+    }
+    if (!a.empty() && a[0] == '-') return die("unknown option " + a);
+    pos.push_back(a);
+  }
+  if (pos.size() != 2) return die("usage: yahr input output [-p MODE]   (two positional arguments required)");
+  if (mode != "sequential" && mode != "eval" && mode != "par" && mode != "hip")
+    return die("Non-exhaustive patterns in case (parallel mode \"" + mode + "\")");   // main.hs:134-137
+  if (threads < 1) threads = 1;
+
+  const char *len_env = std::getenv("YAHR_LENIENT");
+  yahr_host_scene *hs = nullptr;
+  if (yahr_scene_load(pos[0].c_str(), len_env && std::atoi(len_env) != 0, &hs) != YAHR_OK) return die(yahr_last_error());
+  const yahr_scene *flat = yahr_scene_flat(hs);
+  if (!flat) { std::string e = yahr_last_error(); yahr_scene_free(hs); return die(e); }
+
+  int n_dev = yahr_device_count();
+  if (n_dev < 1) { yahr_scene_free(hs); return die("no HIP device available (this build has no CPU path)"); }
+  if (const char *e = std::getenv("YAHR_DEVICES")) { int want = std::atoi(e); if (want >= 1 && want < n_dev) n_dev = want; }
+
+  yahr_render_opts opts; yahr_default_opts(&opts);
+  if (const char *e = std::getenv("YAHR_SPP")) { int s = std::atoi(e); if (s >= 1) opts.spp = s; }
+  const int n_batches = yahr_n_batches(threads, flat->width, flat->height);
+  // main.hs:140-141 prints this line before the (lazy) render is forced
+  std::printf("%d threads, %d batches, parallel %s\n", threads, n_batches, mode.c_str());
+  std::fflush(stdout);
+
+  std::vector<float> rgb((size_t)flat->width * flat->height * 3, 0.0f);
+  yahr_stats st;
+  int rc = yahr_render_multi(flat, n_dev, &opts, rgb.data(), &st);
+  if (rc != YAHR_OK) { std::string e = yahr_last_error(); yahr_scene_free(hs); return die(e); }
+  const double rays = (double)(st.primary_rays + st.reflection_rays + st.shadow_rays);
+  std::fprintf(stderr, "yahr-hip: %d x gfx950, %dx%d, %.3f ms kernel, %.1f Mrays/s, %.1f Mpixels/s\n", n_dev,
+               flat->width, flat->height, st.kernel_ms, st.kernel_ms > 0 ? rays / st.kernel_ms / 1e3 : 0.0,
+               st.kernel_ms > 0 ? (double)flat->width * flat->height / st.kernel_ms / 1e3 : 0.0);
+
+  if (flat->width <= 0 || flat->height <= 0) { yahr_scene_free(hs); return die("image has zero size"); }
+  if (ends_with(pos[1], ".ppm")) rc = yahr_write_ppm(pos[1].c_str(), rgb.data(), flat->width, flat->height);
+  else if (ends_with(pos[1], ".pfm")) rc = yahr_write_pfm(pos[1].c_str(), rgb.data(), flat->width, flat->height);
+  else rc = yahr_write_png(pos[1].c_str(), rgb.data(), flat->width, flat->height);   // savePngImage (main.hs:142)
+  yahr_scene_free(hs);
+  if (rc != YAHR_OK) return die(yahr_last_error());
+  return 0;
+}

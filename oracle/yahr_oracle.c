@@ -392,6 +392,25 @@ static int collide_node(const oscene *s, const onode *nd, oray ray, ohit *out, o
   return have;
 }
 
+/* Optional first-hit variant of the same traversal, used ONLY to validate the HIP kernel's box/primitive
+ * counters (its shadow rays stop at the first accepted primitive).  Same Bool as the full traversal:
+ * once collideAll holds a Just it never returns to Nothing (Rays.hs:42-46). */
+static int g_shadow_any_hit = 0;
+void oracle_set_shadow_any_hit(int on) { g_shadow_any_hit = on; }
+static int any_node(const oscene *s, const onode *nd, oray ray, octx *cx) {
+  ohit h;
+  if (nd->kind == N_NULL) return 0;
+  cx->st.box_tests++;
+  if (!bb_ray(nd->bb, ray, NULL)) return 0;
+  if (nd->kind == N_SINGLE) return collide_prim(s, nd->prims[0], ray, &h, cx);
+  if (nd->kind == N_MULTI) {
+    for (int i = 0; i < nd->nprims; ++i) if (collide_prim(s, nd->prims[i], ray, &h, cx)) return 1;
+    return 0;
+  }
+  if (any_node(s, nd->l, ray, cx)) return 1;
+  return any_node(s, nd->r, ray, cx);
+}
+
 static int root_collide(const oscene *s, oray ray, ohit *out, octx *cx) {
   if (!s->root) return 0;                                                    /* bvh _ _ [] = const Nothing :28 */
   return collide_node(s, s->root, ray, out, cx);
@@ -403,6 +422,7 @@ static int reachable(const oscene *s, ovec3 p0, ovec3 p1, octx *cx) {
   probe.x0 = p0;
   probe.u = norm(vsub(p1, p0));
   probe.tmax = len(vsub(p1, p0));
+  if (g_shadow_any_hit) return !(s->root && any_node(s, s->root, probe, cx));
   return !root_collide(s, probe, &h, cx);
 }
 

@@ -60,6 +60,8 @@ int oracle_scene_n_prims(const oscene *s);
 /* read back primitive i as 19 floats: kind(0 tri,1 sphere), p0 p1 p2 n0 n1 n2 (or c, r) */
 void oracle_scene_get_prim(const oscene *s, int i, float out[19], int32_t *mat);
 void oracle_scene_build(oscene *s);                      /* Culling.hs:21-54, forced eagerly */
+/* counters only: let shadow probes stop at the first accepted primitive (same Bool; see .c) */
+void oracle_set_shadow_any_hit(int on);
 
 /* ---- rendering (main.hs:65-107) */
 void oracle_scene_size(const oscene *s, int32_t *w, int32_t *h);

@@ -55,6 +55,7 @@ def lib():
             "oracle_scene_n_prims": (C.c_int, [C.c_void_p]),
             "oracle_scene_get_prim": (None, [C.c_void_p, C.c_int, _F, _I]),
             "oracle_scene_build": (None, [C.c_void_p]),
+            "oracle_set_shadow_any_hit": (None, [C.c_int]),
             "oracle_scene_size": (None, [C.c_void_p, _I, _I]),
             "oracle_render": (None, [C.c_void_p, C.c_int, C.c_uint32, C.c_int, _F, C.POINTER(OStats)]),
             "oracle_render_rows": (None, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, _F, C.POINTER(OStats)]),

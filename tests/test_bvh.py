@@ -1,0 +1,104 @@
+"""Host BVH build + flattening (yahr_amd/csrc/host_scene.cpp) against the oracle's literal closure tree
+(Culling.hs:21-112).  Node order, boxes, leaf contents and skip links must agree exactly.  CPU only."""
+import numpy as np
+import pytest
+
+import yahr_amd
+from oracle_py import OracleScene
+from yahr_amd import scenes
+
+
+def check_against_oracle(desc):
+    a = desc.to_scene().build().arrays()
+    tr = OracleScene.from_desc(desc).build().tree()
+    n = len(tr["kind"])
+    assert n == len(a["node_a"])
+    leaf = tr["kind"] != 0
+    assert np.array_equal(leaf, a["node_b"] >= 0)
+    assert np.array_equal(tr["first"][leaf], a["node_b"][leaf])
+    assert np.array_equal(tr["count"][leaf], a["node_a"][leaf])
+    assert np.array_equal(tr["boxes"][:, :3].view(np.uint32), a["node_lo"].view(np.uint32))
+    assert np.array_equal(tr["boxes"][:, 3:].view(np.uint32), a["node_hi"].view(np.uint32))
+    assert np.array_equal(tr["prim"], a["prim_orig"])
+    # skip links: subtree end computed independently from the preorder kinds
+    end = np.zeros(n, dtype=np.int64)
+
+    def walk(i):
+        if tr["kind"][i] != 0:
+            end[i] = i + 1
+            return i + 1
+        j = walk(i + 1)
+        j = walk(j)
+        end[i] = j
+        return j
+    import sys
+    sys.setrecursionlimit(10000)
+    if n:
+        assert walk(0) == n
+    inner = ~leaf
+    assert np.array_equal(a["node_a"][inner], end[inner])
+    assert (a["node_b"][inner] == -1).all()
+    return a
+
+
+@pytest.mark.parametrize("split", ["Midpoint", "SurfaceAreaHeuristic"])
+def test_spec_sphere_grid(split):
+    a = check_against_oracle(scenes.spec_sphere_grid(split))
+    assert a["node_a"][a["node_b"] >= 0].sum() == 200
+
+
+@pytest.mark.parametrize("split", ["Midpoint", "SurfaceAreaHeuristic"])
+def test_small_scenes(split):
+    for d in (scenes.scene_fixed(16, 16), scenes.spheres8(16, 9), scenes.test_yahr_scene()):
+        check_against_oracle(d.with_(split=split))
+
+
+@pytest.mark.parametrize("split,depth", [("Midpoint", 16), ("SurfaceAreaHeuristic", 16), ("Midpoint", 3), ("SurfaceAreaHeuristic", 0)])
+def test_pseudo_bunny(split, depth):
+    a = check_against_oracle(scenes.pseudo_bunny(32, 18, bvh_depth=depth, split=split))
+    assert len(a["prim_orig"]) == 69698 and sorted(a["prim_orig"]) == list(range(69698))
+
+
+def test_random_triangles_depth_cap():
+    a = check_against_oracle(scenes.random_tris(30000, 32, 18, bvh_depth=9))
+    assert (a["node_b"] >= 0).sum() <= 2 ** 9          # depth cap => at most 2^d leaves (Culling.hs:34)
+
+
+def test_degenerate_inputs():
+    base = scenes.scene_fixed(8, 8)
+    # all primitives share one centroid: every split sends everything left -> multiLeaf (Culling.hs:36-37)
+    same = [("sphere", (1, 2, 3), float(r), "sphere") for r in (1, 2, 3, 4, 5, 6)]
+    for split in ("Midpoint", "SurfaceAreaHeuristic"):
+        a = check_against_oracle(base.with_(objects=same, split=split))
+        assert len(a["node_a"]) == 1 and a["node_a"][0] == 6 and a["node_b"][0] == 0
+    # no objects: bvh _ _ [] = const Nothing (Culling.hs:28) -> zero nodes
+    a = check_against_oracle(base.with_(objects=[]))
+    assert len(a["node_a"]) == 0
+    # one object: singleton leaf
+    a = check_against_oracle(base.with_(objects=same[:1]))
+    assert len(a["node_a"]) == 1 and a["node_a"][0] == 1
+    # NaN coordinates must not crash or desynchronise the two builders
+    weird = same[:3] + [("sphere", (float("nan"), 0, 0), 1.0, "sphere"), ("sphere", (0, float("inf"), 0), 1.0, "sphere")]
+    for split in ("Midpoint", "SurfaceAreaHeuristic"):
+        check_against_oracle(base.with_(objects=weird, split=split))
+
+
+def test_hypothesis_random_scenes():
+    hyp = pytest.importorskip("hypothesis")
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=40, deadline=None)
+    @given(st.integers(0, 2 ** 32 - 1), st.integers(1, 300), st.integers(0, 8), st.booleans())
+    def inner(seed, n, depth, sah):
+        rng = np.random.default_rng(seed)
+        objs = []
+        for _ in range(n):
+            if rng.random() < 0.3:
+                objs.append(("sphere", tuple(rng.integers(-4, 5, 3).astype(float)), float(rng.integers(1, 3)), "sphere"))
+            else:
+                p = rng.integers(-6, 7, (3, 3)).astype(np.float32)     # integer grid: many exact ties
+                nn = (0.0, 1.0, 0.0)
+                objs.append(("triangle", tuple(p[0]), tuple(p[1]), tuple(p[2]), nn, nn, nn, "bottom"))
+        d = scenes.scene_fixed(8, 8).with_(objects=objs, bvh_depth=depth, split="SurfaceAreaHeuristic" if sah else "Midpoint")
+        check_against_oracle(d)
+    inner()

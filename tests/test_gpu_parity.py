@@ -147,7 +147,7 @@ def test_unknown_material_is_an_error_only_when_shaded(gpu):
     img, _ = gpu_render(hidden)                                        # never hit: renders fine (lazy Map.!)
     ref, _ = oracle_render(base)
     assert outside_tol(img, ref) == 0
-    visible = base.with_(objects=[("sphere", (0, -1.2, 10), 1.0, "no-such-material")] + base.objects)
+    visible = base.with_(objects=[("sphere", (1.0, -1.0, 7), 1.0, "no-such-material")] + base.objects)
     with pytest.raises(yahr_amd.YahrError) as e:
         gpu_render(visible)
     assert e.value.code == -7 and "Map.!" in str(e.value)
@@ -324,9 +324,9 @@ def test_full_size_properties(gpu, bunny_full):
     lights4 = [(p, tuple(4.0 * c for c in s)) for p, s in d.lights]
     img4, _ = yahr_amd.render_image(d.with_(lights=lights4).to_scene().build())
     assert np.array_equal(bits(img4), bits(img * np.float32(4.0)))
-    # pixels covered: sky is black, floor and bunny are lit
-    assert img[:300].max() == 0.0 or img[:100].max() == 0.0
-    assert (img.sum(axis=2) > 0).mean() > 0.3
+    # background is black (miss = 0, Integrators.hs:29), floor and bunny are lit
+    lit = (img.sum(axis=2) > 0).mean()
+    assert 0.3 < lit < 0.95 and not img[0, :8].any()
 
 
 def test_full_size_shards_assemble(gpu, bunny_full):

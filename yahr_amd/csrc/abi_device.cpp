@@ -195,7 +195,7 @@ static int ensure_windows(yahr_ctx *c, int n_batches) {
 }
 
 int yahr_ctx_render(yahr_ctx *c, int32_t row0, int32_t row1, const yahr_render_opts *opts_in, float *d_rgb, void *hip_stream) {
-  if (!c || !d_rgb) { set_error("null argument"); return YAHR_E_ARG; }
+  if (!c) { set_error("null argument"); return YAHR_E_ARG; }
   yahr_render_opts o; if (opts_in) o = *opts_in; else yahr_default_opts(&o);
   if (o.spp < 1) { set_error("spp must be >= 1"); return YAHR_E_ARG; }
   hipStream_t st = (hipStream_t)hip_stream;
@@ -227,7 +227,8 @@ int yahr_ctx_render(yahr_ctx *c, int32_t row0, int32_t row1, const yahr_render_o
     rp.n_tiles = rp.tiles_x * ((rp.n_local_rows + 7) / 8);
     n_blocks = ((rp.n_tiles + 7) / 8) * 8;     // the XCD swizzle needs a multiple of 8 blocks
   }
-  if (n_blocks == 0 || c->width == 0) return YAHR_OK;
+  if (n_blocks == 0 || c->width == 0 || rp.n_local_rows == 0) return YAHR_OK;   // nothing to render
+  if (!d_rgb) { set_error("null output buffer"); return YAHR_E_ARG; }
   HIP_TRY(hipEventRecord(c->ev0, st));
   HIP_TRY(yahr_dev::launch_render(c->ds, rp, pick_mode(o.traverse), n_blocks, d_rgb, c->d_ctr, o.collect_stats != 0, st));
   HIP_TRY(hipEventRecord(c->ev1, st));

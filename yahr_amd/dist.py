@@ -5,7 +5,7 @@ The reference parallelises over independent pixel tiles inside one process (main
 is cut into strips of `strip_rows` rows dealt round-robin to the ranks (strip s -> rank s % world), every
 rank renders its strips with the scene replicated in its own HBM, and there is exactly ONE collective per
 frame: a gather of the float RGB strips to rank 0, which scatters them to their image rows
-(samplesToImage, main.hs:98-107).  No exchange step exists inside the frame.
+(samplesToImage, main.hs:98-107) with a single index_copy.  No exchange step exists inside the frame.
 """
 import torch
 import torch.distributed as dist
@@ -18,36 +18,49 @@ class ShardPlan:
 
     def __init__(self, height, width, world, strip_rows=8, device="cpu"):
         self.height, self.width, self.world, self.strip_rows = height, width, world, strip_rows
+        self.device = torch.device(device)
         self.rows = [shard_rows(height, world, r, strip_rows) for r in range(world)]
         self.max_rows = max(self.rows) if self.rows else 0
         assert sum(self.rows) == height
-        # destination row of every (rank, local row) in gather order; padding rows are dropped
-        idx = [torch.from_numpy(shard_global_rows(height, world, r, strip_rows)) for r in range(world)]
-        self.dest = [i.to(device) for i in idx]
-
-    def assemble(self, parts):
-        """parts[r]: [max_rows or rows[r], width, 3] tensor of rank r -> full image [height, width, 3]"""
-        img = torch.empty((self.height, self.width, 3), dtype=parts[0].dtype, device=parts[0].device)
-        for r, p in enumerate(parts):
+        # destination row of every (rank, local row) in gather order; padding rows go to a scratch row
+        dest = torch.full((world, self.max_rows), height, dtype=torch.int64)
+        for r in range(world):
             if self.rows[r]:
-                img.index_copy_(0, self.dest[r], p[: self.rows[r]])
-        return img
+                dest[r, : self.rows[r]] = torch.from_numpy(shard_global_rows(height, world, r, strip_rows))
+        self.dest = dest.reshape(-1).to(self.device)
+
+    def buffers(self, rank):
+        """(local strip buffer, gather buffer [world, max_rows, w, 3] on rank 0, image buffer with a scratch row)"""
+        local = torch.zeros((self.max_rows, self.width, 3), dtype=torch.float32, device=self.device)
+        if rank != 0:
+            return local, None, None
+        gathered = torch.zeros((self.world, self.max_rows, self.width, 3), dtype=torch.float32, device=self.device)
+        image = torch.zeros((self.height + 1, self.width, 3), dtype=torch.float32, device=self.device)
+        return local, gathered, image
+
+    def assemble(self, parts, image=None):
+        """parts: [world, max_rows, width, 3] tensor (or a list of per-rank [>=rows[r], width, 3] tensors).
+        Returns the full image [height, width, 3] (a view of `image` when given)."""
+        if isinstance(parts, (list, tuple)):
+            buf = torch.zeros((self.world, self.max_rows, self.width, 3), dtype=parts[0].dtype, device=parts[0].device)
+            for r, p in enumerate(parts):
+                buf[r, : self.rows[r]] = p[: self.rows[r]]
+            parts = buf
+        if image is None:
+            image = torch.empty((self.height + 1, self.width, 3), dtype=parts.dtype, device=parts.device)
+        image.index_copy_(0, self.dest.to(parts.device), parts.reshape(-1, self.width, 3))
+        return image[: self.height]
 
 
-def render_sharded(render_fn, plan, rank, group=None, out_buffers=None):
+def render_sharded(render_fn, plan, rank, group=None, bufs=None):
     """render_fn(shard, n_shards, strip_rows, out) renders this rank's strips into `out`
-    ([max_rows, width, 3], rows beyond plan.rows[rank] are padding).  Returns the assembled image on rank 0,
+    ([max_rows, width, 3]; rows beyond plan.rows[rank] are padding).  Returns the assembled image on rank 0,
     None elsewhere.  One gather per call."""
-    if out_buffers is None:
-        dev = plan.dest[0].device
-        local = torch.zeros((plan.max_rows, plan.width, 3), dtype=torch.float32, device=dev)
-        parts = [torch.empty_like(local) for _ in range(plan.world)] if rank == 0 else None
-    else:
-        local, parts = out_buffers
+    local, gathered, image = bufs if bufs is not None else plan.buffers(rank)
     render_fn(rank, plan.world, plan.strip_rows, local)
     if plan.world == 1:
-        return plan.assemble([local])
-    dist.gather(local, gather_list=parts if rank == 0 else None, dst=0, group=group)
+        return local[: plan.height]
+    dist.gather(local, gather_list=[gathered[r] for r in range(plan.world)] if rank == 0 else None, dst=0, group=group)
     if rank != 0:
         return None
-    return plan.assemble(parts)
+    return plan.assemble(gathered, image)

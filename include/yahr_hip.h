@@ -179,7 +179,8 @@ typedef struct yahr_render_opts {
   /* row sharding: the image is cut into strips of strip_rows rows; this call renders the strips s with
    * s % n_shards == shard, compacted top to bottom into the output.  n_shards <= 1: rows [row0,row1). */
   int32_t n_shards, shard, strip_rows;
-  int32_t reserved[7];
+  int32_t tuning;              /* 0 = defaults; bit 0: XCD band swizzle of the tile order (diagnostics: slower) */
+  int32_t reserved[6];
 } yahr_render_opts;
 
 typedef struct yahr_stats {
@@ -190,6 +191,7 @@ typedef struct yahr_stats {
   uint64_t bad_material;                                 /* shaded hits on mat == -1 */
   double kernel_ms;                                      /* device time of the render launch(es), HIP events */
   double upload_ms;                                      /* one-shot calls: host->device scene copy */
+  uint64_t max_wave_cycles, sum_wave_cycles;             /* shader clocks of the longest wavefront / of all (collect_stats only) */
 } yahr_stats;
 
 void yahr_default_opts(yahr_render_opts *o);

@@ -82,7 +82,7 @@ class Scene:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and lib is not None:           # lib is None during interpreter shutdown
             lib.yahr_scene_free(h)
 
     @classmethod
@@ -200,12 +200,13 @@ class Scene:
 
 
 def make_opts(spp=1, seed=0, traverse=TRAVERSE_AUTO, tiles=TILES_WAVE, n_batches=0, collect_stats=False,
-              n_shards=1, shard=0, strip_rows=8):
+              n_shards=1, shard=0, strip_rows=8, tuning=0):
     o = RenderOpts()
     lib.yahr_default_opts(C.byref(o))
     o.spp, o.seed, o.traverse, o.tiles, o.n_batches = spp, seed, traverse, tiles, n_batches
     o.collect_stats = int(collect_stats)
     o.n_shards, o.shard, o.strip_rows = n_shards, shard, strip_rows
+    o.tuning = tuning
     return o
 
 
@@ -222,7 +223,7 @@ class Context:
 
     def close(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and lib is not None:
             lib.yahr_ctx_destroy(h)
 
     def __del__(self):

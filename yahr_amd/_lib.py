@@ -56,14 +56,15 @@ class RenderOpts(C.Structure):
     _fields_ = [("spp", C.c_int32), ("seed", C.c_uint32), ("traverse", C.c_int32), ("tiles", C.c_int32),
                 ("n_batches", C.c_int32), ("collect_stats", C.c_int32),
                 ("n_shards", C.c_int32), ("shard", C.c_int32), ("strip_rows", C.c_int32),
-                ("reserved", C.c_int32 * 7)]
+                ("tuning", C.c_int32), ("reserved", C.c_int32 * 6)]
 
 
 class Stats(C.Structure):
     _fields_ = [("primary_rays", C.c_uint64), ("reflection_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
                 ("box_tests", C.c_uint64), ("tri_tests", C.c_uint64), ("sphere_tests", C.c_uint64),
                 ("shaded_hits", C.c_uint64), ("wave_node_steps", C.c_uint64), ("wave_prim_steps", C.c_uint64),
-                ("bad_material", C.c_uint64), ("kernel_ms", C.c_double), ("upload_ms", C.c_double)]
+                ("bad_material", C.c_uint64), ("kernel_ms", C.c_double), ("upload_ms", C.c_double),
+                ("max_wave_cycles", C.c_uint64), ("sum_wave_cycles", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -20,8 +20,9 @@ struct yahr_ctx {
   DScene ds{};
   int width = 0, height = 0;
   void *d_nodes = nullptr, *d_prims = nullptr, *d_normals = nullptr, *d_mats = nullptr, *d_lights = nullptr;
+  void *d_cold = nullptr;
   unsigned long long *d_ctr = nullptr;
-  int4 *d_windows = nullptr; int n_windows = 0, windows_w = 0, windows_h = 0;
+  int4 *d_windows = nullptr; int n_windows = 0, n_chunks = 0, windows_w = 0, windows_h = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
   double upload_ms = 0;
@@ -63,11 +64,12 @@ int check_scene(const yahr_scene *s) {
   return YAHR_OK;
 }
 
-int upload(void **dst, const void *src, size_t bytes) {
+// copies `bytes` and appends `pad` zero bytes (one padding record: the kernel prefetches "the next record")
+int upload(void **dst, const void *src, size_t bytes, size_t pad = 64) {
   *dst = nullptr;
-  if (bytes == 0) bytes = 16;   // keep pointers non-null
-  HIP_TRY(hipMalloc(dst, bytes));
-  if (src) HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(dst, bytes + pad));
+  HIP_TRY(hipMemset((char *)*dst + bytes, 0, pad));
+  if (src && bytes) HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
   return YAHR_OK;
 }
 
@@ -137,20 +139,17 @@ int yahr_ctx_create(const yahr_scene *s, int device, yahr_ctx **out) {
       (rc = upload(&c->d_normals, s->normals, sizeof(yahr_prim_normals) * (size_t)s->n_prims)) ||
       (rc = upload(&c->d_mats, s->mats, sizeof(yahr_material) * (size_t)s->n_mats)) ||
       (rc = upload(&c->d_lights, s->lights, sizeof(yahr_light) * (size_t)s->n_lights)) ||
-      (rc = upload((void **)&c->d_ctr, nullptr, sizeof(unsigned long long) * CTR_COUNT))) {
+      (rc = upload((void **)&c->d_ctr, nullptr, sizeof(unsigned long long) * CTR_TOTAL))) {
     yahr_ctx_destroy(c); return rc;
   }
-  HIP_TRY(hipMemset(c->d_ctr, 0, sizeof(unsigned long long) * CTR_COUNT));
+  HIP_TRY(hipMemset(c->d_ctr, 0, sizeof(unsigned long long) * CTR_TOTAL));
   HIP_TRY(hipEventRecord(u1, nullptr));
   HIP_TRY(hipEventSynchronize(u1));
   float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, u0, u1)); c->upload_ms = ms;
   hipEventDestroy(u0); hipEventDestroy(u1);
   HIP_TRY(hipEventCreate(&c->ev0)); HIP_TRY(hipEventCreate(&c->ev1));
-  DScene &d = c->ds;
-  d.nodes = (const float4 *)c->d_nodes; d.prims = (const float4 *)c->d_prims; d.normals = (const float4 *)c->d_normals;
-  d.mats = (const float4 *)c->d_mats; d.lights = (const float4 *)c->d_lights;
-  d.n_nodes = s->n_nodes; d.n_prims = s->n_prims; d.n_mats = s->n_mats; d.n_lights = s->n_lights;
-  d.depth = s->depth;
+  DCold cold{};
+  cold.mats = (const float4 *)c->d_mats; cold.lights = (const float4 *)c->d_lights;
   // origin = transformPoint tf (Vec3 0 0 0)  (Cameras.hs:84), same left fold as the device's transform_point
   {
     float tv[4];
@@ -161,10 +160,16 @@ int yahr_ctx_create(const yahr_scene *s, int device, yahr_ctx **out) {
       tv[i] = acc;
     }
     float iw = 1.0f / tv[3];
-    d.origin[0] = iw * tv[0]; d.origin[1] = iw * tv[1]; d.origin[2] = iw * tv[2];
+    cold.origin[0] = iw * tv[0]; cold.origin[1] = iw * tv[1]; cold.origin[2] = iw * tv[2];
   }
-  std::memcpy(d.vtf, s->cam_vtf, sizeof d.vtf);
-  d.focal = s->focal;
+  std::memcpy(cold.vtf, s->cam_vtf, sizeof cold.vtf);
+  cold.focal = s->focal;
+  if ((rc = upload(&c->d_cold, &cold, sizeof cold))) { yahr_ctx_destroy(c); return rc; }
+  DScene &d = c->ds;
+  d.nodes = (const float4 *)c->d_nodes; d.prims = (const float4 *)c->d_prims; d.normals = (const float4 *)c->d_normals;
+  d.cold = (const DCold *)c->d_cold;
+  d.n_nodes = s->n_nodes; d.n_prims = s->n_prims; d.n_mats = s->n_mats; d.n_lights = s->n_lights;
+  d.depth = s->depth;
   *out = c;
   return YAHR_OK;
 }
@@ -173,7 +178,7 @@ void yahr_ctx_destroy(yahr_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipFree(c->d_nodes); (void)hipFree(c->d_prims); (void)hipFree(c->d_normals); (void)hipFree(c->d_mats);
-  (void)hipFree(c->d_lights); (void)hipFree(c->d_ctr); (void)hipFree(c->d_windows);
+  (void)hipFree(c->d_lights); (void)hipFree(c->d_ctr); (void)hipFree(c->d_windows); (void)hipFree(c->d_cold);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   delete c;
@@ -182,15 +187,20 @@ void yahr_ctx_destroy(yahr_ctx *c) {
 // Prepare the reference's squareBatches windows on the device (outside any capture).
 static int ensure_windows(yahr_ctx *c, int n_batches) {
   if (c->d_windows && c->n_windows == n_batches && c->windows_w == c->width && c->windows_h == c->height) return YAHR_OK;
-  std::vector<int4> win((size_t)n_batches);
+  // one wavefront per 64-pixel chunk of a window: {x0,y0,x1,y1}, {first pixel, batch, 0, 0}
+  std::vector<int4> win;
   for (int b = 0; b < n_batches; ++b) {
     int32_t w4[4]; yahr_batch_window(c->width, c->height, b, n_batches, w4);
-    win[(size_t)b] = make_int4(w4[0], w4[1], w4[2], w4[3]);
+    const int64_t npx = (int64_t)(w4[2] - w4[0]) * (w4[3] - w4[1]);
+    for (int64_t p0 = 0; p0 < npx; p0 += 64) {
+      win.push_back(make_int4(w4[0], w4[1], w4[2], w4[3]));
+      win.push_back(make_int4((int)p0, b, 0, 0));
+    }
   }
   if (c->d_windows) { HIP_TRY(hipFree(c->d_windows)); c->d_windows = nullptr; }
-  HIP_TRY(hipMalloc((void **)&c->d_windows, sizeof(int4) * (size_t)n_batches));
-  HIP_TRY(hipMemcpy(c->d_windows, win.data(), sizeof(int4) * (size_t)n_batches, hipMemcpyHostToDevice));
-  c->n_windows = n_batches; c->windows_w = c->width; c->windows_h = c->height;
+  HIP_TRY(hipMalloc((void **)&c->d_windows, sizeof(int4) * (win.size() + 2)));
+  if (!win.empty()) HIP_TRY(hipMemcpy(c->d_windows, win.data(), sizeof(int4) * win.size(), hipMemcpyHostToDevice));
+  c->n_windows = n_batches; c->n_chunks = (int)(win.size() / 2); c->windows_w = c->width; c->windows_h = c->height;
   return YAHR_OK;
 }
 
@@ -204,14 +214,17 @@ int yahr_ctx_render(yahr_ctx *c, int32_t row0, int32_t row1, const yahr_render_o
   rp.width = c->width; rp.height = c->height;
   rp.spp = o.spp; rp.seed = o.seed;
   { int n = (int)std::floor(std::sqrt((double)o.spp) + 0.5); rp.n_strata = (n * n == o.spp) ? n : 1; }
-  rp.xcd_swizzle = 1;
+  // Measured on the pseudo-bunny: giving each XCD a contiguous band of tile rows loses 7-20 % (blocks go to
+  // XCDs round-robin, statically, and image regions differ in cost by orders of magnitude), so the natural
+  // tile order -- neighbouring tiles on different XCDs, perfectly balanced -- is the default.
+  rp.xcd_swizzle = (o.tuning & 1) ? 1 : 0;
   int n_blocks = 0;
   if (o.tiles == YAHR_TILES_REFERENCE) {
     if (o.n_shards > 1 || row0 != 0 || row1 != c->height) { set_error("reference tiles render the whole image only"); return YAHR_E_ARG; }
     int nb = o.n_batches > 0 ? o.n_batches : yahr_n_batches(1, c->width, c->height);
     int rc = ensure_windows(c, nb); if (rc) return rc;
     rp.tile_mode = 1; rp.windows = c->d_windows; rp.n_local_rows = c->height; rp.strip_rows = c->height > 0 ? c->height : 1; rp.n_shards = 1;
-    n_blocks = nb;
+    n_blocks = c->n_chunks;
   } else {
     if (o.n_shards > 1) {
       if (o.shard < 0 || o.shard >= o.n_shards || o.strip_rows <= 0) { set_error("bad shard spec"); return YAHR_E_ARG; }
@@ -240,7 +253,7 @@ int yahr_ctx_stats(yahr_ctx *c, yahr_stats *out) {
   if (!c || !out) { set_error("null argument"); return YAHR_E_ARG; }
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipDeviceSynchronize());
-  unsigned long long h[CTR_COUNT];
+  unsigned long long h[CTR_TOTAL];
   HIP_TRY(hipMemcpy(h, c->d_ctr, sizeof h, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemset(c->d_ctr, 0, sizeof h));
   std::memset(out, 0, sizeof *out);
@@ -248,6 +261,7 @@ int yahr_ctx_stats(yahr_ctx *c, yahr_stats *out) {
   out->shaded_hits = h[CTR_SHADED]; out->bad_material = h[CTR_BAD_MAT];
   out->box_tests = h[CTR_BOX]; out->tri_tests = h[CTR_TRI]; out->sphere_tests = h[CTR_SPH];
   out->wave_node_steps = h[CTR_WAVE_NODES]; out->wave_prim_steps = h[CTR_WAVE_PRIMS];
+  out->max_wave_cycles = h[CTR_MAX_WAVE_CYCLES]; out->sum_wave_cycles = h[CTR_SUM_WAVE_CYCLES];
   if (c->timed) { float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1)); out->kernel_ms = ms; }
   out->upload_ms = c->upload_ms;
   if (out->bad_material) {

@@ -71,6 +71,23 @@ YD bool tri_candidate(V3 p0, V3 e1, V3 e2, V3 o, V3 u, float tmax, float &t, flo
   return b0 >= 0.0f && b0 <= 1.0f && b1 >= 0.0f && b1 <= 1.0f && b2 >= 0.0f && b2 <= 1.0f &&
          t > 0.0f && t <= tmax;
 }
+// The same test cut in two for the packet walker (identical operations and values, only regrouped): stage 1
+// needs s, s1, the determinant and its reciprocal and yields b1 with its range test; when no lane of the
+// wavefront passes it the caller skips stage 2 (s2, t, b2, b0 and their tests) with a wave-uniform branch.
+YD bool tri_stage1(V3 p0, V3 e1, V3 e2, V3 o, V3 u, V3 &s, float &inv, float &b1) {
+  s = o - p0;
+  const V3 s1 = cross(u, e2);
+  inv = 1.0f / dot(s1, e1);
+  b1 = dot(s1, s) * inv;
+  return b1 >= 0.0f && b1 <= 1.0f;
+}
+YD bool tri_stage2(V3 e1, V3 e2, V3 s, V3 u, float inv, float b1, float tmax, float &t, float &b2) {
+  const V3 s2 = cross(s, e1);
+  t = dot(s2, e2) * inv;
+  b2 = dot(s2, u) * inv;
+  const float b0 = (1.0f - b1) - b2;
+  return b0 >= 0.0f && b0 <= 1.0f && b2 >= 0.0f && b2 <= 1.0f && t > 0.0f && t <= tmax;
+}
 YD V3 tri_shading_normal(float b1, float b2, V3 n0, V3 n1, V3 n2) {                  // Shapes.hs:47-48
   float b0 = (1.0f - b1) - b2;
   return (scale(b0, n0) + scale(b1, n1)) + scale(b2, n2);

@@ -15,9 +15,21 @@
 //                    with scalar loads (wave-uniform address) into SGPRs, every lane tests its own ray,
 //                    `v_cmp` + vcc!=0 decides "descend" for the wave, and a per-lane `wake` index
 //                    (the skip link of the subtree the lane missed) masks lanes that are not inside
-//                    the current subtree.  Preorder indices only grow, so lane is active iff wake<=i.
+//                    the current subtree.  Preorder indices only grow, so a lane is active iff wake<=i.
 // Equal-t ties, t<=tMax acceptance, back-face culling and NaN behaviour therefore match the oracle
 // bit for bit; shadow rays stop at the first accepted primitive (same Bool as Rays.hs:49-54).
+//
+// What bounds this kernel (rocprofv3 PMC, profiles/): not bytes -- the whole scene sits in L2/MALL and the
+// frame moves ~75 MB over HBM -- but the serial instruction chain of the heaviest wavefronts: a wave issues
+// one instruction per ~4 clocks, and a tile over dense geometry walks thousands of dependent node/primitive
+// steps.  So the code is shaped for FEW INSTRUCTIONS PER STEP:
+//   * each walker is instantiated once per kernel (radiance is a wave-uniform state machine with a single
+//     traversal call site; first-hit mode is a run-time flag; one pixel loop for all tilings / sample counts);
+//   * the fast build carries no counters at all (ray and test counts come from the collect_stats build);
+//   * scene fields used only between traversals live behind one pointer (DCold), not in argument SGPRs;
+//   * record arrays are padded by one record, so prefetching "the next record" needs no clamp;
+//   * the slab test runs branch-free for all lanes and is masked afterwards;
+//   * the triangle test is cut in two stages with a wave-uniform exit between them.
 #include <hip/hip_runtime.h>
 
 #include "device_math.hpp"
@@ -27,60 +39,112 @@
 
 using namespace yd;
 
+// Tuning knobs (compile time).  YAHR_WAVES: waves per SIMD the register allocator must make room for.
+#ifndef YAHR_WAVES
+#define YAHR_WAVES 4
+#endif
+#define YAHR_KERNEL_ATTR __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(YAHR_WAVES, 8)))
+
 namespace {
 
 struct Hit { int prim; float t, b1, b2; };   // prim = leaf-order record index, -1 = Nothing
 
+// Counters exist in collect_stats builds only.  Ray counters are wave-uniform SGPR accumulators, updated
+// at wave-uniform program points with the popcount of a lane mask; the per-test counters are per lane
+// because they are bumped inside divergent control flow.
 struct Counters {
-  unsigned primary, reflection, shadow, shaded, bad_mat;
-  unsigned box, tri, sph, wave_nodes, wave_prims;
+  unsigned primary, reflection, shadow, shaded, wave_nodes, wave_prims;   // uniform
+  unsigned box, tri, sph;                                                 // per lane
 };
+YD unsigned lanes(bool p) { return (unsigned)__popcll(__ballot(p)); }
 
 YD V3 ld3(const float4 *p) { float4 v = *p; return v3(v.x, v.y, v.z); }
 
-// accept test for one primitive record against one ray.  Returns true and updates (hit, tmax) on accept.
+struct NodeRec { float4 lo, hi; };            // yahr_node as two 16-byte words
+struct PrimRec { float4 r0, r1, r2; };        // yahr_prim as three 16-byte words
+YD NodeRec load_node(const DScene &sc, int i) {
+  NodeRec n; n.lo = sc.nodes[2 * (size_t)i]; n.hi = sc.nodes[2 * (size_t)i + 1]; return n;
+}
+YD PrimRec load_prim(const DScene &sc, int i) {
+  PrimRec p; const float4 *pr = sc.prims + 3 * (size_t)i; p.r0 = pr[0]; p.r1 = pr[1]; p.r2 = pr[2]; return p;
+}
+
+// Cold scene block.  (Do NOT launder this pointer through an `asm volatile`: the statement counts as a
+// possible clobber and the compiler then refuses scalar loads for every scene array -- measured.)
+YD const DCold *cold_of(const DScene &sc) { return sc.cold; }
+
+// ---- accept tests ---------------------------------------------------------------------------------
+// second half of collideTriangle for a lane that passed every geometric test: interpolated normal and
+// back-face cull (Shapes.hs:47-48,57); updates (hit, tmax) on accept
+YD bool tri_accept(const DScene &sc, int idx, V3 u, float t, float b1, float b2, float &tmax, Hit &hit) {
+  const float4 *nr = sc.normals + 3 * (size_t)idx;
+  const V3 ns = tri_shading_normal(b1, b2, ld3(nr), ld3(nr + 1), ld3(nr + 2));
+  if (!(dot(u, ns) < 0.0f)) return false;
+  hit.prim = idx; hit.t = t; hit.b1 = b1; hit.b2 = b2; tmax = t;
+  return true;
+}
+
+// one primitive against one ray, lane walker form
 template <bool STATS>
-YD bool test_prim(const DScene &sc, int idx, float4 r0, float4 r1, float4 r2, V3 o, V3 u, float &tmax,
-                  Hit &hit, Counters &c) {
-  int kind = __float_as_int(r1.w);
-  if (kind == 0) {
+YD bool test_prim_lane(const DScene &sc, int idx, const PrimRec &p, V3 o, V3 u, float &tmax, Hit &hit, Counters &c) {
+  if (__float_as_int(p.r1.w) == 0) {
     if (STATS) c.tri++;
     float t, b1, b2;
-    if (!tri_candidate(xyz(r0), xyz(r1), xyz(r2), o, u, tmax, t, b1, b2)) return false;
-    const float4 *nr = sc.normals + 3 * (size_t)idx;
-    V3 ns = tri_shading_normal(b1, b2, ld3(nr), ld3(nr + 1), ld3(nr + 2));
-    if (!(dot(u, ns) < 0.0f)) return false;                        // back-face cull, Shapes.hs:57
-    hit.prim = idx; hit.t = t; hit.b1 = b1; hit.b2 = b2; tmax = t;
-    return true;
-  } else {
-    if (STATS) c.sph++;
-    float t;
-    if (!sphere_hit(xyz(r0), r1.x, o, u, tmax, t)) return false;
-    hit.prim = idx; hit.t = t; hit.b1 = 0.0f; hit.b2 = 0.0f; tmax = t;
-    return true;
+    if (!tri_candidate(xyz(p.r0), xyz(p.r1), xyz(p.r2), o, u, tmax, t, b1, b2)) return false;
+    return tri_accept(sc, idx, u, t, b1, b2, tmax, hit);
   }
+  if (STATS) c.sph++;
+  float t;
+  if (!sphere_hit(xyz(p.r0), p.r1.x, o, u, tmax, t)) return false;
+  hit.prim = idx; hit.t = t; hit.b1 = 0.0f; hit.b2 = 0.0f; tmax = t;
+  return true;
+}
+
+// one (wave-uniform) primitive against the rays of the lanes with `live` set, packet walker form.
+// Stage 1 runs branch-free on every lane; stage 2 only if some live lane passed stage 1.
+template <bool STATS>
+YD bool test_prim_packet(const DScene &sc, int idx, const PrimRec &p, bool live, V3 o, V3 u, float &tmax, Hit &hit,
+                         Counters &c) {
+  bool got = false;
+  if (__float_as_int(p.r1.w) == 0) {                                  // wave-uniform branch
+    if (STATS) c.tri += live ? 1u : 0u;
+    V3 s; float inv, b1;
+    const bool p1 = tri_stage1(xyz(p.r0), xyz(p.r1), xyz(p.r2), o, u, s, inv, b1) & live;
+    if (__any(p1)) {
+      float t, b2;
+      const bool p2 = tri_stage2(xyz(p.r1), xyz(p.r2), s, u, inv, b1, tmax, t, b2) & p1;
+      if (p2) got = tri_accept(sc, idx, u, t, b1, b2, tmax, hit);
+    }
+  } else {
+    if (STATS) c.sph += live ? 1u : 0u;
+    if (live) {
+      float t;
+      if (sphere_hit(xyz(p.r0), p.r1.x, o, u, tmax, t)) {
+        hit.prim = idx; hit.t = t; hit.b1 = 0.0f; hit.b2 = 0.0f; tmax = t; got = true;
+      }
+    }
+  }
+  return got;
 }
 
 // ---- lane walker --------------------------------------------------------------------------------
-template <bool ANY, bool STATS>
-YD void traverse_lane(const DScene &sc, bool active, const Ray &ray, Hit &hit, Counters &c) {
-  const V3 o = ray.o, u = ray.d;
+template <bool STATS>
+YD void traverse_lane(const DScene &sc, bool active, bool any_hit, V3 o, V3 u, float tmax, Hit &hit, Counters &c) {
   const V3 inv = v3(1.0f / u.x, 1.0f / u.y, 1.0f / u.z);
-  float tmax = ray.tmax;
   hit.prim = -1; hit.t = 0.0f; hit.b1 = 0.0f; hit.b2 = 0.0f;
   const int n = sc.n_nodes;
   int i = active ? 0 : n;
   while (i < n) {
-    const float4 lo = sc.nodes[2 * (size_t)i], hi = sc.nodes[2 * (size_t)i + 1];
-    const int a = __float_as_int(lo.w), b = __float_as_int(hi.w);
+    const NodeRec nd = load_node(sc, i);
+    const int a = __float_as_int(nd.lo.w), b = __float_as_int(nd.hi.w);
     if (STATS) c.box++;
-    const bool h = slab_hit(xyz(lo), xyz(hi), o, inv, tmax);
+    const bool h = slab_hit(xyz(nd.lo), xyz(nd.hi), o, inv, tmax);
     int next = (b >= 0 || h) ? i + 1 : a;
     if (h && b >= 0) {
       for (int k = 0; k < a; ++k) {
-        const float4 *pr = sc.prims + 3 * (size_t)(b + k);
-        if (test_prim<STATS>(sc, b + k, pr[0], pr[1], pr[2], o, u, tmax, hit, c)) {
-          if (ANY) { next = n; break; }
+        const PrimRec p = load_prim(sc, b + k);
+        if (test_prim_lane<STATS>(sc, b + k, p, o, u, tmax, hit, c)) {
+          if (any_hit) { next = n; break; }
         }
       }
     }
@@ -97,145 +161,170 @@ YD int wave_min_i32(int v) {
   return v;
 }
 
-template <bool ANY, bool STATS>
-YD void traverse_packet(const DScene &sc, bool active, const Ray &ray, Hit &hit, Counters &c) {
-  const V3 o = ray.o, u = ray.d;
+// The node index i is wave-uniform, so node and primitive records arrive through SCALAR loads into SGPRs.
+// The successor in array order (i+1: always the next node after a leaf, and the left child of a hit
+// interior node) and a leaf's first primitive are requested before the slab test of the current node, so
+// that round trip overlaps the VALU work; only a skip needs a dependent load.
+template <bool STATS>
+YD void traverse_packet(const DScene &sc, bool active, bool any_hit, V3 o, V3 u, float tmax, Hit &hit, Counters &c) {
   const V3 inv = v3(1.0f / u.x, 1.0f / u.y, 1.0f / u.z);
-  float tmax = ray.tmax;
   hit.prim = -1; hit.t = 0.0f; hit.b1 = 0.0f; hit.b2 = 0.0f;
   const int n = sc.n_nodes;
+  if (n == 0 || !__any(active)) return;
   int wake = active ? 0 : YD_DONE;
-  if (!__any(active)) return;
   int i = 0;                                           // wave-uniform: lives in an SGPR
-  while (i < n) {
-    const float4 lo = sc.nodes[2 * (size_t)i], hi = sc.nodes[2 * (size_t)i + 1];   // scalar loads
-    const int a = __float_as_int(lo.w), b = __float_as_int(hi.w);
+  NodeRec cur = load_node(sc, 0);
+  for (;;) {
+    const int a = __float_as_int(cur.lo.w), b = __float_as_int(cur.hi.w);
+    const NodeRec nseq = load_node(sc, i + 1);         // padded array: in bounds even for the last node
+    PrimRec pcur;
+    if (b >= 0) pcur = load_prim(sc, b);               // leaf: first primitive (padded array)
     const bool on = wake <= i;
     if (STATS) { c.box += on ? 1u : 0u; c.wave_nodes++; }
-    const bool h = on && slab_hit(xyz(lo), xyz(hi), o, inv, tmax);
+    const bool h = slab_hit(xyz(cur.lo), xyz(cur.hi), o, inv, tmax) & on;   // branch-free, masked afterwards
     const bool anyh = __any(h);
-    if (b >= 0) {                                      // leaf (uniform branch)
+    int next = i + 1;
+    if (b >= 0) {                                      // leaf (wave-uniform branch)
       if (anyh) {
         bool got = false;
         for (int k = 0; k < a; ++k) {
-          const float4 *pr = sc.prims + 3 * (size_t)(b + k);                       // scalar loads
-          const float4 r0 = pr[0], r1 = pr[1], r2 = pr[2];
+          const PrimRec pnext = load_prim(sc, b + k + 1);                    // prefetch (padded array)
           if (STATS) c.wave_prims++;
-          if (h && !(ANY && got)) got |= test_prim<STATS>(sc, b + k, r0, r1, r2, o, u, tmax, hit, c);
+          const bool live = h & !(any_hit & got);
+          got |= test_prim_packet<STATS>(sc, b + k, pcur, live, o, u, tmax, hit, c);
+          pcur = pnext;
         }
-        if (ANY && got) wake = YD_DONE;
-        if (ANY && __any(got)) {
-          const int m = wave_min_i32(wake);            // next node any lane still needs
-          if (m == YD_DONE) break;
-          i = __builtin_amdgcn_readfirstlane(m > i + 1 ? m : i + 1);
-          continue;
+        if (any_hit) {
+          if (got) wake = YD_DONE;
+          if (__any(got)) {
+            // next node any lane still needs; readfirstlane tells the compiler the minimum is wave-uniform
+            // (otherwise the loop exit looks divergent and every node load degrades to a per-lane gather)
+            const int m = __builtin_amdgcn_readfirstlane(wave_min_i32(wake));
+            if (m == YD_DONE) break;
+            if (m > next) next = m;
+          }
         }
       }
-      i = i + 1;
     } else {
-      if (on && !h) wake = a;
-      i = anyh ? i + 1 : a;
+      wake = (on & !h) ? a : wake;
+      next = anyh ? i + 1 : a;
     }
+    if (next >= n) break;
+    if (next == i + 1) cur = nseq; else cur = load_node(sc, next);
+    i = next;
   }
 }
 
-template <int MODE, bool ANY, bool STATS>
-YD void traverse(const DScene &sc, bool active, const Ray &ray, Hit &hit, Counters &c, int ray_class) {
-  // ray_class: 0 primary, 1 shadow, 2 reflection
-  if (MODE == TRAV_LANE) traverse_lane<ANY, STATS>(sc, active, ray, hit, c);
-  else if (MODE == TRAV_PACKET) traverse_packet<ANY, STATS>(sc, active, ray, hit, c);
+// ray_class: 0 primary, 1 shadow, 2 reflection
+template <int MODE, bool STATS>
+YD void traverse(const DScene &sc, bool active, bool any_hit, V3 o, V3 u, float tmax, Hit &hit, Counters &c, int ray_class) {
+  if (MODE == TRAV_LANE) traverse_lane<STATS>(sc, active, any_hit, o, u, tmax, hit, c);
+  else if (MODE == TRAV_PACKET) traverse_packet<STATS>(sc, active, any_hit, o, u, tmax, hit, c);
   else {  // hybrid: coherent ray classes as packets, reflection rays per lane
-    if (ray_class == 2) traverse_lane<ANY, STATS>(sc, active, ray, hit, c);
-    else traverse_packet<ANY, STATS>(sc, active, ray, hit, c);
+    if (ray_class == 2) traverse_lane<STATS>(sc, active, any_hit, o, u, tmax, hit, c);
+    else traverse_packet<STATS>(sc, active, any_hit, o, u, tmax, hit, c);
   }
 }
 
 // ---- shading --------------------------------------------------------------------------------------
-struct Surface { V3 x, n, dpdu; V3 diffuse, specular; float shininess; };
-
-// DifferentialGeometry of the accepted hit (Shapes.hs:23-28, 49-55) + its material (main.hs:55-60)
-YD Surface surface_of(const DScene &sc, const Ray &ray, const Hit &hit, Counters &c) {
-  Surface s;
-  const float4 *pr = sc.prims + 3 * (size_t)hit.prim;
-  const float4 r0 = pr[0], r1 = pr[1], r2 = pr[2];
-  const int mat = __float_as_int(r0.w);
-  s.x = ray.o + scale(hit.t, ray.d);                                  // dgPoint / rayAt
-  if (__float_as_int(r1.w) == 0) {
+// DifferentialGeometry of the accepted hit (Shapes.hs:23-28, 49-55); returns the material index
+YD int surface_of(const DScene &sc, V3 ro, V3 rd, const Hit &hit, V3 &x, V3 &n, V3 &dpdu) {
+  const PrimRec p = load_prim(sc, hit.prim);
+  x = ro + scale(hit.t, rd);                                          // dgPoint / rayAt
+  if (__float_as_int(p.r1.w) == 0) {
     const float4 *nr = sc.normals + 3 * (size_t)hit.prim;
     V3 ns = tri_shading_normal(hit.b1, hit.b2, ld3(nr), ld3(nr + 1), ld3(nr + 2));
-    V3 ss = norm(xyz(r2));                                            // norm e2
+    V3 ss = norm(xyz(p.r2));                                          // norm e2
     V3 ts = norm(cross(ss, ns));
-    s.n = ns;                                                         // NOT normalised (Shapes.hs:53)
-    s.dpdu = cross(ts, ns);
+    n = ns;                                                           // NOT normalised (Shapes.hs:53)
+    dpdu = cross(ts, ns);
   } else {
-    V3 nn = norm(s.x - xyz(r0));
-    s.n = nn;
-    s.dpdu = cross(nn, v3(0.0f, 0.0f, 1.0f));
+    V3 nn = norm(x - xyz(p.r0));
+    n = nn;
+    dpdu = cross(nn, v3(0.0f, 0.0f, 1.0f));
   }
+  return __float_as_int(p.r0.w);
+}
+
+// BSDF.at (blinnPhong material) dg wi wo   (Shaders.hs:12-14, BSDF.hs:12-46); mat < 0: unknown material
+YD V3 material_at(const DScene &sc, int mat, V3 n, V3 dpdu, V3 wi, V3 wo) {
+  V3 diffuse = vof(0.0f), specular = vof(0.0f); float shininess = 0.0f;
   if (mat >= 0) {
-    const float4 m0 = sc.mats[2 * (size_t)mat], m1 = sc.mats[2 * (size_t)mat + 1];
-    s.diffuse = xyz(m0); s.shininess = m0.w; s.specular = xyz(m1);
-  } else {
-    c.bad_mat++;
-    s.diffuse = vof(0.0f); s.specular = vof(0.0f); s.shininess = 0.0f;
+    const float4 *mats = cold_of(sc)->mats;
+    const float4 m0 = mats[2 * (size_t)mat], m1 = mats[2 * (size_t)mat + 1];
+    diffuse = xyz(m0); shininess = m0.w; specular = xyz(m1);
   }
-  return s;
+  const Frame fr = bsdf_frame(n, dpdu);
+  return blinn_phong_at(diffuse, specular, shininess, fr, wi, wo);
 }
 
 // Integrators.radiance for one primary ray per lane (vcast/vhit, Integrators.hs:22-43).
 // The recursion is linear, so it runs as a loop; per level k the lane stores w_k = (n.r) @* f r and
 // D_k = directIllumination in LDS and the result is folded back-to-front: v = w_k * v + D_k, which is
 // exactly `(n .* r) @* f r * rs + direct` evaluated in the reference's order.
+//
+// Wave-uniform state machine with ONE traversal call site.  step = k*(L+1) + phase:
+//   phase 0      closest hit of the level-k ray, then DifferentialGeometry of the hit
+//   phase 1..L   shadow probe towards light phase-1 (Lights.hs:15-24, Rays.hs:49-54); its contribution
+//                cv = |lightDir.n| @* k * intensity is formed BEFORE the probe so that only cv stays live
+//   after phase L: w_k, D_k to LDS, reflection ray (Integrators.hs:40-47)
 template <int MODE, bool STATS>
-YD V3 radiance(const DScene &sc, bool valid, Ray ray, float *lds, int lane, Counters &c) {
+YD V3 radiance(const DScene &sc, bool valid, V3 ro, V3 rd, float *lds, int lane, Counters &c, bool &bad_mat) {
   bool alive = valid;
   int levels = 0;
-  for (int k = 0; k < sc.depth; ++k) {
-    if (!__any(alive)) break;
-    Hit hit;
-    if (alive) { if (k == 0) c.primary++; else c.reflection++; }
-    traverse<MODE, false, STATS>(sc, alive, ray, hit, c, k == 0 ? 0 : 2);
-    alive = alive && hit.prim >= 0;
-    Surface s; Frame fr; V3 wo = vneg(ray.d), r = vof(0.0f), direct = vof(0.0f);
-    if (alive) {
-      c.shaded++;
-      s = surface_of(sc, ray, hit, c);
-      fr = bsdf_frame(s.n, s.dpdu);
-      r = ray.d - scale(2.0f * dot(ray.d, s.n), s.n);                 // reflectionDir, Integrators.hs:46-47
-    }
-    // directIllumination (Integrators.hs:50-61): sum = foldl (+) 0 over the lights, in order
-    for (int li = 0; li < sc.n_lights; ++li) {
-      const float4 l0 = sc.lights[2 * (size_t)li], l1 = sc.lights[2 * (size_t)li + 1];
-      V3 kf = vof(0.0f), ldir = vof(0.0f), intensity = vof(0.0f);
-      bool need = false;
-      Ray probe; probe.o = vof(0.0f); probe.d = v3(0.0f, 0.0f, 1.0f); probe.tmax = 0.0f;
+  const int L = sc.n_lights, per = L + 1, n_steps = sc.depth * per;
+  V3 x = vof(0.0f), n = vof(0.0f), dpdu = vof(0.0f), direct = vof(0.0f), cv = vof(0.0f);
+  int mat = -1;
+  for (int step = 0; step < n_steps; ++step) {
+    const int k = step / per, phase = step - k * per;
+    V3 qo = ro, qd = rd; float qt = 1e6f; bool active;
+    if (phase == 0) {
+      if (!__any(alive)) break;
+      if (STATS) { if (k == 0) c.primary += lanes(alive); else c.reflection += lanes(alive); }
+      active = alive;
+      direct = vof(0.0f);
+    } else {
+      active = false;
       if (alive) {
-        V3 p2l = xyz(l0) - s.x;                                       // Lights.hs:17-19
-        ldir = norm(p2l);
-        intensity = scale(1.0f / lensq(p2l), xyz(l1));
-        kf = blinn_phong_at(s.diffuse, s.specular, s.shininess, fr, ldir, wo);
-        need = lensq(kf) > 0.0f;                                      // && is lazy: probe only if k != 0
-        if (need) {
-          V3 p0 = s.x + scale(0.001f, ldir);                          // reachable, Rays.hs:49-54
-          V3 dd = xyz(l0) - p0;
-          probe.o = p0; probe.d = norm(dd); probe.tmax = len(dd);
-          c.shadow++;
+        const float4 *lights = cold_of(sc)->lights;
+        const float4 l0 = lights[2 * (size_t)(phase - 1)], l1 = lights[2 * (size_t)(phase - 1) + 1];
+        const V3 p2l = xyz(l0) - x;                                   // Lights.hs:17-19
+        const V3 ldir = norm(p2l);
+        const V3 intensity = scale(1.0f / lensq(p2l), xyz(l1));
+        const V3 kf = material_at(sc, mat, n, dpdu, ldir, vneg(rd));  // Integrators.hs:58
+        active = lensq(kf) > 0.0f;                                    // && is lazy: probe only if k /= 0
+        if (active) {
+          const V3 p0 = x + scale(0.001f, ldir);                      // reachable, Rays.hs:49-54
+          const V3 dd = xyz(l0) - p0;
+          qo = p0; qd = norm(dd); qt = len(dd);
+          cv = scale(fabsf(dot(ldir, n)), kf) * intensity;            // Integrators.hs:60
         }
       }
-      Hit sh;
-      traverse<MODE, true, STATS>(sc, need, probe, sh, c, 1);
-      V3 contrib = vof(0.0f);
-      if (need && sh.prim < 0) contrib = scale(fabsf(dot(ldir, s.n)), kf) * intensity;
-      if (alive) direct = direct + contrib;
+      if (STATS) c.shadow += lanes(active);
     }
-    if (alive) {
-      V3 f_r = blinn_phong_at(s.diffuse, s.specular, s.shininess, fr, r, wo);
-      V3 w = scale(dot(s.n, r), f_r);
+    Hit hit;
+    traverse<MODE, STATS>(sc, active, phase != 0, qo, qd, qt, hit, c, phase != 0 ? 1 : (k == 0 ? 0 : 2));
+    if (phase == 0) {
+      alive = alive && hit.prim >= 0;
+      if (STATS) c.shaded += lanes(alive);
+      if (alive) {
+        mat = surface_of(sc, ro, rd, hit, x, n, dpdu);
+        // Map.! on a missing key (main.hs:55).  Only a lane flag here: a store inside this loop would make
+        // every later scene load "clobberable" and ban the scalar-load path of the packet walker.
+        bad_mat = bad_mat | (mat < 0);
+      }
+    } else if (alive) {
+      direct = direct + ((active && hit.prim < 0) ? cv : vof(0.0f));  // sum = foldl (+) 0, light order
+    }
+    if (phase == L && alive) {
+      const V3 r = rd - scale(2.0f * dot(rd, n), n);                  // reflectionDir, Integrators.hs:46-47
+      const V3 f_r = material_at(sc, mat, n, dpdu, r, vneg(rd));
+      const V3 w = scale(dot(n, r), f_r);
       float *slot = lds + (size_t)k * 6 * 64 + lane;
       slot[0] = w.x; slot[64] = w.y; slot[128] = w.z;
       slot[192] = direct.x; slot[256] = direct.y; slot[320] = direct.z;
       levels = k + 1;
-      ray.o = s.x + scale(0.001f, r); ray.d = r; ray.tmax = 1e6f;     // Integrators.hs:41-43
+      ro = x + scale(0.001f, r); rd = r;                              // Integrators.hs:41-43
     }
   }
   V3 v = vof(0.0f);                                                   // vcast 0 _ = 0 / miss = 0
@@ -247,25 +336,11 @@ YD V3 radiance(const DScene &sc, bool valid, Ray ray, float *lds, int lane, Coun
   return v;
 }
 
-YD Ray camera_ray(const DScene &sc, float fu, float fv) {              // Cameras.hs:83-86
-  Ray r;
-  V3 origin = v3(sc.origin[0], sc.origin[1], sc.origin[2]);
-  V3 direction = transform_point(sc.vtf, v3(fu, fv, sc.focal)) - origin;
-  r.o = origin; r.d = norm(direction); r.tmax = 1e6f;
-  return r;
-}
-
-template <int MODE, bool STATS>
-YD V3 render_pixel(const DScene &sc, const RParams &rp, bool valid, int u, int gv, float *lds, int lane, Counters &c) {
-  if (rp.spp <= 1)                                                     // main.hs:73: the integer pixel corner
-    return radiance<MODE, STATS>(sc, valid, camera_ray(sc, (float)u, (float)gv), lds, lane, c);
-  V3 acc = vof(0.0f);
-  for (int k = 0; k < rp.spp; ++k) {
-    float du, dv;
-    sample_offset(u, gv, k, rp.n_strata, rp.seed, du, dv);
-    acc = acc + radiance<MODE, STATS>(sc, valid, camera_ray(sc, (float)u + du, (float)gv + dv), lds, lane, c);
-  }
-  return scale(1.0f / (float)rp.spp, acc);
+YD void camera_ray(const DScene &sc, float fu, float fv, V3 &ro, V3 &rd) {   // Cameras.hs:83-86
+  const DCold *cold = cold_of(sc);
+  const V3 origin = v3(cold->origin[0], cold->origin[1], cold->origin[2]);
+  const V3 direction = transform_point(cold->vtf, v3(fu, fv, cold->focal)) - origin;
+  ro = origin; rd = norm(direction);
 }
 
 YD unsigned wave_sum_u32(unsigned v) {
@@ -275,65 +350,80 @@ YD unsigned wave_sum_u32(unsigned v) {
 }
 
 YD void flush_counters(const Counters &c, unsigned long long *ctr, int lane) {
-  unsigned vals[CTR_COUNT] = {c.primary, c.reflection, c.shadow, c.shaded, c.bad_mat,
-                              c.box, c.tri, c.sph, c.wave_nodes, c.wave_prims};
+  const unsigned box = wave_sum_u32(c.box), tri = wave_sum_u32(c.tri), sph = wave_sum_u32(c.sph);
+  const unsigned vals[CTR_COUNT] = {c.primary, c.reflection, c.shadow, c.shaded, 0u,
+                                    box, tri, sph, c.wave_nodes, c.wave_prims};
+  if (lane == 0) {
 #pragma unroll
-  for (int i = 0; i < CTR_COUNT; ++i) {
-    unsigned s = (i == CTR_WAVE_NODES || i == CTR_WAVE_PRIMS) ? __builtin_amdgcn_readfirstlane(vals[i]) : wave_sum_u32(vals[i]);
-    if (lane == 0 && s) atomicAdd(&ctr[i], (unsigned long long)s);
+    for (int i = 0; i < CTR_COUNT; ++i)
+      if (vals[i]) atomicAdd(&ctr[i], (unsigned long long)vals[i]);
   }
 }
 
 }  // namespace
 
-// One wavefront (= one 64-thread workgroup) per tile.
+// One wavefront (= one 64-thread workgroup) per tile: an 8x8-pixel tile, or one of the reference's
+// squareBatches windows (Sampling.hs:5-21) walked 64 pixels at a time, u-major like the reference.
 template <int MODE, bool STATS>
-__global__ __launch_bounds__(64) void k_render(DScene sc, RParams rp, float *__restrict__ out,
-                                               unsigned long long *__restrict__ ctr) {
+__global__ YAHR_KERNEL_ATTR void k_render(DScene sc, RParams rp, float *__restrict__ out,
+                                          unsigned long long *__restrict__ ctr) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x;
   Counters c = {};
+  bool bad_mat = false;
+  const unsigned long long t_start = STATS ? clock64() : 0ULL;
+  int tile = blockIdx.x;
+  if (rp.tile_mode == 0 && rp.xcd_swizzle) {           // diagnostics: contiguous band of tiles per XCD
+    const int per = (rp.n_tiles + 7) >> 3;
+    tile = (tile & 7) * per + (tile >> 3);
+  }
+  // NOTE: the ONLY global stores of this kernel come after the last traversal.  A store (or atomic) ahead of
+  // a scene load makes that load "clobberable" for the compiler, which then refuses the scalar-load path and
+  // silently turns the packet walker's node fetches into per-lane gathers (tests/test_isa.py guards this).
+  int u, gv; size_t row; bool valid;
   if (rp.tile_mode == 0) {
-    // 8x8-pixel tile per wavefront; consecutive blocks go to different XCDs (round-robin dispatch), so
-    // the tile order is permuted to give each XCD a compact band of tile rows (L2 locality).
-    int b = blockIdx.x;
-    int tile = b;
-    if (rp.xcd_swizzle) {
-      const int per = (rp.n_tiles + 7) >> 3;
-      tile = (b & 7) * per + (b >> 3);
-    }
-    if (tile < rp.n_tiles) {
-      const int ty = tile / rp.tiles_x, tx = tile - ty * rp.tiles_x;
-      const int u = tx * 8 + (lane & 7);
-      const int lv = ty * 8 + (lane >> 3);
-      // local row -> global image row (row sharding, include/yahr_hip.h yahr_render_opts)
-      const int strip = lv / rp.strip_rows;
-      const int gv = rp.row0 + strip * rp.strip_rows * rp.n_shards + (lv - strip * rp.strip_rows);
-      const bool valid = u < rp.width && lv < rp.n_local_rows && gv < rp.height;
-      V3 v = render_pixel<MODE, STATS>(sc, rp, valid, u, gv, lds, lane, c);
-      if (valid) {
-        float *px = out + ((size_t)lv * rp.width + u) * 3;              // samplesToImage: w*v+u (main.hs:100)
-        px[0] = v.x; px[1] = v.y; px[2] = v.z;
-      }
-    }
+    const int ty = tile / rp.tiles_x, tx = tile - ty * rp.tiles_x;
+    u = tx * 8 + (lane & 7);
+    const int lv = ty * 8 + (lane >> 3);
+    // local row -> global image row (row sharding, include/yahr_hip.h yahr_render_opts)
+    const int strip = lv / rp.strip_rows;
+    gv = rp.row0 + strip * rp.strip_rows * rp.n_shards + (lv - strip * rp.strip_rows);
+    valid = tile < rp.n_tiles && u < rp.width && lv < rp.n_local_rows && gv < rp.height;
+    row = (size_t)lv;
   } else {
-    // the reference's squareBatches window for this batch (Sampling.hs:5-21), u-major inside the window
-    const int4 win = rp.windows[blockIdx.x];
-    const int ww = win.z - win.x, hh = win.w - win.y;
-    const int npx = ww * hh;
-    for (int p0 = 0; p0 < npx; p0 += 64) {
-      const int p = p0 + lane;
-      const bool valid = p < npx;
-      const int u = valid ? win.x + p / hh : 0;
-      const int gv = valid ? win.y + p % hh : 0;
-      V3 v = render_pixel<MODE, STATS>(sc, rp, valid, u, gv, lds, lane, c);
-      if (valid) {
-        float *px = out + ((size_t)gv * rp.width + u) * 3;
-        px[0] = v.x; px[1] = v.y; px[2] = v.z;
-      }
+    // 64-pixel chunk of a reference window: {x0,y0,x1,y1}, {first pixel of the chunk, ...}; u-major order
+    const int4 win = rp.windows[2 * (size_t)tile], q = rp.windows[2 * (size_t)tile + 1];
+    const int hh = win.w - win.y, npx = (win.z - win.x) * hh;
+    const int p = q.x + lane;
+    valid = p < npx;
+    u = valid ? win.x + p / hh : 0;
+    gv = valid ? win.y + p % hh : 0;
+    row = (size_t)gv;
+  }
+  V3 acc = vof(0.0f);
+  for (int s = 0; s < rp.spp; ++s) {
+    float du = 0.0f, dv = 0.0f;                        // spp == 1: the integer pixel corner (main.hs:73)
+    if (rp.spp > 1) sample_offset(u, gv, s, rp.n_strata, rp.seed, du, dv);
+    V3 ro, rd;
+    camera_ray(sc, (float)u + du, (float)gv + dv, ro, rd);
+    const V3 v = radiance<MODE, STATS>(sc, valid, ro, rd, lds, lane, c, bad_mat);
+    acc = (rp.spp > 1) ? acc + v : v;
+  }
+  if (rp.spp > 1) acc = scale(1.0f / (float)rp.spp, acc);
+  if (valid) {
+    float *px = out + (row * rp.width + u) * 3;          // samplesToImage: w*v+u (main.hs:100)
+    px[0] = acc.x; px[1] = acc.y; px[2] = acc.z;
+  }
+  const unsigned n_bad = lanes(bad_mat);
+  if (n_bad && lane == 0) atomicAdd(&ctr[CTR_BAD_MAT], (unsigned long long)n_bad);
+  if (STATS) {
+    flush_counters(c, ctr, lane);
+    if (lane == 0) {                                   // critical-path diagnostics: longest wave, all waves
+      const unsigned long long dt = clock64() - t_start;
+      atomicMax(&ctr[CTR_MAX_WAVE_CYCLES], dt);
+      atomicAdd(&ctr[CTR_SUM_WAVE_CYCLES], dt);
     }
   }
-  flush_counters(c, ctr, lane);
 }
 
 // ---- diagnostic kernels: device functions on arbitrary rays (KAT checks on the GPU) -----------------
@@ -342,37 +432,40 @@ __global__ __launch_bounds__(64) void k_trace(DScene sc, int n, const float *__r
                                               int *__restrict__ prim_out, float *__restrict__ t_out) {
   const int i = blockIdx.x * 64 + threadIdx.x;
   const bool valid = i < n;
-  Ray r; r.o = vof(0.0f); r.d = v3(0, 0, 1); r.tmax = 0.0f;
-  if (valid) { const float *p = rays + 7 * (size_t)i; r.o = v3(p[0], p[1], p[2]); r.d = v3(p[3], p[4], p[5]); r.tmax = p[6]; }
+  V3 o = vof(0.0f), d = v3(0, 0, 1); float tmax = 0.0f;
+  if (valid) { const float *p = rays + 7 * (size_t)i; o = v3(p[0], p[1], p[2]); d = v3(p[3], p[4], p[5]); tmax = p[6]; }
   Hit h; Counters c = {};
-  if (any_hit) traverse<MODE, true, false>(sc, valid, r, h, c, 1);
-  else traverse<MODE, false, false>(sc, valid, r, h, c, 0);
+  traverse<MODE, false>(sc, valid, any_hit != 0, o, d, tmax, h, c, any_hit ? 1 : 0);
   if (valid) {
     prim_out[i] = h.prim >= 0 ? __float_as_int(sc.prims[3 * (size_t)h.prim + 2].w) : -1;
     if (t_out) t_out[i] = h.t;
   }
 }
 
+// radiance of arbitrary rays; tMax of the given ray is ignored (the integrator casts with 1e6, like vcast)
 template <int MODE>
 __global__ __launch_bounds__(64) void k_radiance(DScene sc, int n, const float *__restrict__ rays,
                                                  float *__restrict__ rgb, unsigned long long *__restrict__ ctr) {
   extern __shared__ float lds[];
   const int i = blockIdx.x * 64 + threadIdx.x;
   const bool valid = i < n;
-  Ray r; r.o = vof(0.0f); r.d = v3(0, 0, 1); r.tmax = 0.0f;
-  if (valid) { const float *p = rays + 7 * (size_t)i; r.o = v3(p[0], p[1], p[2]); r.d = v3(p[3], p[4], p[5]); r.tmax = p[6]; }
+  V3 ro = vof(0.0f), rd = v3(0, 0, 1);
+  if (valid) { const float *p = rays + 7 * (size_t)i; ro = v3(p[0], p[1], p[2]); rd = v3(p[3], p[4], p[5]); }
   Counters c = {};
-  V3 v = radiance<MODE, false>(sc, valid, r, lds, threadIdx.x, c);
+  bool bad_mat = false;
+  V3 v = radiance<MODE, false>(sc, valid, ro, rd, lds, threadIdx.x, c, bad_mat);
   if (valid) { rgb[3 * (size_t)i] = v.x; rgb[3 * (size_t)i + 1] = v.y; rgb[3 * (size_t)i + 2] = v.z; }
-  flush_counters(c, ctr, threadIdx.x);
+  const unsigned n_bad = lanes(bad_mat);
+  if (n_bad && threadIdx.x == 0) atomicAdd(&ctr[CTR_BAD_MAT], (unsigned long long)n_bad);
 }
 
 __global__ void k_camera_rays(DScene sc, int n, const float *__restrict__ uv, float *__restrict__ rays) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  Ray r = camera_ray(sc, uv[2 * (size_t)i], uv[2 * (size_t)i + 1]);
+  V3 ro, rd;
+  camera_ray(sc, uv[2 * (size_t)i], uv[2 * (size_t)i + 1], ro, rd);
   float *p = rays + 7 * (size_t)i;
-  p[0] = r.o.x; p[1] = r.o.y; p[2] = r.o.z; p[3] = r.d.x; p[4] = r.d.y; p[5] = r.d.z; p[6] = r.tmax;
+  p[0] = ro.x; p[1] = ro.y; p[2] = ro.z; p[3] = rd.x; p[4] = rd.y; p[5] = rd.z; p[6] = 1e6f;
 }
 
 // ---- launchers (called from abi_device.cpp) -------------------------------------------------------

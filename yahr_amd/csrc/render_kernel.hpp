@@ -3,18 +3,27 @@
 
 #include <hip/hip_runtime.h>
 
-// device view of a yahr_scene (include/yahr_hip.h); every record array is read as float4 words
+// Scene fields that are only touched between traversals (camera, lights, materials).  They live in device
+// memory behind ONE pointer instead of in the kernel-argument SGPRs: the traversal loop is SGPR-hungry
+// (node and primitive records are scalar), and 25 pinned argument registers were being spilled to VGPR lanes.
+struct DCold {
+  const float4 *mats;      // 2 per yahr_material
+  const float4 *lights;    // 2 per yahr_light
+  float origin[3];         // transformPoint tf (Vec3 0 0 0)   (Cameras.hs:84)
+  float focal;
+  float vtf[16];           // Cameras.hs:81
+};
+
+// device view of a yahr_scene (include/yahr_hip.h); every record array is read as float4 words.
+// nodes and prims carry ONE zeroed padding record at the end so that "next record" prefetches never need a
+// bounds clamp.
 struct DScene {
   const float4 *nodes;     // 2 per yahr_node
   const float4 *prims;     // 3 per yahr_prim
   const float4 *normals;   // 3 per yahr_prim_normals
-  const float4 *mats;      // 2 per yahr_material
-  const float4 *lights;    // 2 per yahr_light
+  const DCold *cold;
   int n_nodes, n_prims, n_mats, n_lights;
   int depth;
-  float origin[3];         // transformPoint tf (Vec3 0 0 0)   (Cameras.hs:84)
-  float vtf[16];           // Cameras.hs:81
-  float focal;
 };
 
 struct RParams {
@@ -32,7 +41,9 @@ struct RParams {
 enum { TRAV_LANE = 1, TRAV_PACKET = 2, TRAV_HYBRID = 3 };
 
 enum { CTR_PRIMARY = 0, CTR_REFLECTION, CTR_SHADOW, CTR_SHADED, CTR_BAD_MAT,
-       CTR_BOX, CTR_TRI, CTR_SPH, CTR_WAVE_NODES, CTR_WAVE_PRIMS, CTR_COUNT };
+       CTR_BOX, CTR_TRI, CTR_SPH, CTR_WAVE_NODES, CTR_WAVE_PRIMS, CTR_COUNT,
+       // appended after the summed counters: per-wave shader-clock statistics (collect_stats builds)
+       CTR_MAX_WAVE_CYCLES = CTR_COUNT, CTR_SUM_WAVE_CYCLES, CTR_TOTAL };
 
 namespace yahr_dev {
 hipError_t launch_render(const DScene &sc, const RParams &rp, int mode, int n_blocks, float *out,

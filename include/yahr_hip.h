@@ -179,8 +179,14 @@ typedef struct yahr_render_opts {
   /* row sharding: the image is cut into strips of strip_rows rows; this call renders the strips s with
    * s % n_shards == shard, compacted top to bottom into the output.  n_shards <= 1: rows [row0,row1). */
   int32_t n_shards, shard, strip_rows;
-  int32_t tuning;              /* 0 = defaults; bit 0: XCD band swizzle of the tile order (diagnostics: slower) */
-  int32_t reserved[6];
+  int32_t tuning;              /* 0 = defaults; bit 0: XCD band swizzle of the tile order (diagnostics: slower);
+                                  bit 1: dispatch centre tile rows first (diagnostics: measured slower) */
+  /* Frame batch: frames > 1 renders that many frames in ONE launch (tiles of all frames interleaved, so the
+   * tail of one frame overlaps the others).  Frame f lands at d_rgb + f * frame_rows * width * 3 and uses camera f of
+   * yahr_ctx_set_cameras (the scene camera when none were set).  0 and 1 mean a single frame. */
+  int32_t frames;
+  int32_t frame_rows;          /* rows between consecutive frames in d_rgb; 0 = packed (the rows rendered) */
+  int32_t reserved[4];
 } yahr_render_opts;
 
 typedef struct yahr_stats {
@@ -212,6 +218,10 @@ int32_t yahr_shard_global_row(int32_t local, int32_t n_shards, int32_t shard, in
  * default stream); no host synchronisation, no allocation: usable inside hipGraph capture. */
 int yahr_ctx_render(yahr_ctx *ctx, int32_t row0, int32_t row1, const yahr_render_opts *opts,
                     float *d_rgb, void *hip_stream);
+/* Cameras for frame batches (opts->frames > 1): n cameras of 12 floats each -- imW imH focalLength lookDir[3]
+ * upDir[3] position[3] (Cameras.hs:54-56); floor imW/imH must equal the scene's image size.  n = 0 clears them.
+ * Synchronous; call it outside stream capture. */
+int yahr_ctx_set_cameras(yahr_ctx *ctx, int32_t n, const float *cameras);
 /* Counters of the launches since the last call (synchronises the device). */
 int yahr_ctx_stats(yahr_ctx *ctx, yahr_stats *out);
 

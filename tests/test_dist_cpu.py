@@ -34,16 +34,18 @@ def _worker(rank, world, port, w, h, strip, out_path):
         from yahr_amd import shard_global_rows
         desc = scenes.scene_fixed(w, h)
         osc = OracleScene.from_desc(desc).build()
-        plan = ShardPlan(h, w, world, strip)
+        plan = ShardPlan(h, w, world, strip, frames=2)
 
         def render_fn(shard, n_shards, strip_rows, out):
             rows = shard_global_rows(h, n_shards, shard, strip_rows)
             for i, gv in enumerate(rows):                      # oracle stand-in for the HIP launch
                 r, _ = osc.render_rows(int(gv), int(gv) + 1, threads=1)
-                out[i] = torch.from_numpy(r[0])
+                for f in range(out.shape[0]):                  # every frame of the batch (same camera here)
+                    out[f, i] = torch.from_numpy(r[0])
         img = render_sharded(render_fn, plan, rank)
         if rank == 0:
-            np.save(out_path, img.numpy())
+            assert img.shape[0] == plan.frames and all(torch.equal(img[0], img[f]) for f in range(plan.frames))
+            np.save(out_path, img[0].numpy())
         else:
             assert img is None
         dist.barrier()
@@ -66,5 +68,5 @@ def test_plan_single_rank_is_identity():
     plan = ShardPlan(11, 4, 1, 8)
     x = torch.arange(11 * 4 * 3, dtype=torch.float32).reshape(11, 4, 3)
     assert torch.equal(plan.assemble([x]), x)
-    img = render_sharded(lambda s, n, st, out: out.copy_(x), plan, 0)
-    assert torch.equal(img, x)
+    img = render_sharded(lambda s, n, st, out: out.copy_(x.unsqueeze(0)), plan, 0)
+    assert torch.equal(img[0], x)

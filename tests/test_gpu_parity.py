@@ -340,3 +340,42 @@ def test_full_size_shards_assemble(gpu, bunny_full):
     torch.cuda.synchronize()
     assert np.array_equal(bits(out.cpu().numpy()), bits(img))
     ctx.close()
+
+
+# ---- frame batches (one launch, several frames) -------------------------------------------------------------
+def test_frame_batch_equals_single_frames(gpu):
+    import torch
+    d = scenes.scene_fixed(101, 67)
+    scene = d.to_scene().build()
+    ctx = yahr_amd.Context(scene, 0)
+    one = ctx.render().cpu().numpy()
+    for mode in MODES:
+        batch = ctx.render(frames=5, traverse=mode).cpu().numpy()
+        assert batch.shape == (5, 67, 101, 3)
+        for f in range(5):
+            assert np.array_equal(bits(batch[f]), bits(one))
+    # per-frame cameras: every frame must equal a stand-alone render of a scene with that camera
+    cams = [dict(d.camera, pos=(-4 + 0.5 * i, 3, 2), look=(0.4, -0.3 - 0.02 * i, 1)) for i in range(4)]
+    ctx.set_cameras([[c["imW"], c["imH"], c["focal"], *c["look"], *c["up"], *c["pos"]] for c in cams])
+    batch = ctx.render(frames=4).cpu().numpy()
+    for i, c in enumerate(cams):
+        ref_img, _ = yahr_amd.render_image(d.with_camera(**c).to_scene().build())
+        assert np.array_equal(bits(batch[i]), bits(ref_img)), i
+        oref, _ = oracle_render(d.with_camera(**c))
+        assert outside_tol(batch[i], oref) == 0
+    with pytest.raises(yahr_amd.YahrError):
+        ctx.render(frames=6)                                   # more frames than cameras
+    with pytest.raises(yahr_amd.YahrError):
+        ctx.set_cameras([[64, 64, 1, 0, 0, 1, 0, 1, 0, 0, 0, 0]])   # image size differs from the scene's
+    ctx.set_cameras(None)
+    # batches of shards with padded frame stride, as bench.py lays them out
+    from yahr_amd.dist import ShardPlan
+    plan = ShardPlan(scene.height, scene.width, 3, 8, device="cuda:0", frames=2)
+    parts = torch.zeros((3, 2, plan.max_rows, scene.width, 3), device="cuda:0")
+    st = torch.cuda.current_stream()
+    for r in range(3):
+        o = yahr_amd.make_opts(n_shards=3, shard=r, strip_rows=8, frames=2, frame_rows=plan.max_rows)
+        ctx.render_into(parts[r].data_ptr(), 0, scene.height, o, st.cuda_stream)
+    imgs = plan.assemble(parts).cpu().numpy()
+    assert np.array_equal(bits(imgs[0]), bits(one)) and np.array_equal(bits(imgs[1]), bits(one))
+    ctx.close()

@@ -27,12 +27,16 @@ desc = {"bunny": lambda: scenes.pseudo_bunny(), "spheres": lambda: scenes.sphere
         "tris": lambda: scenes.random_tris(), "tris200k": lambda: scenes.random_tris(200000, bvh_depth=16)}[a.scene]()
 scene = desc.to_scene().build()
 ctx = yahr_amd.Context(scene, 0)
-out = torch.zeros((scene.height, scene.width, 3), device="cuda:0")
+MAXF = 32
+out = torch.zeros((MAXF, scene.height, scene.width, 3), device="cuda:0")
 st = torch.cuda.current_stream()
 variants = []
 for v in a.variants:
-    name, tr, tun = v.split(":")
-    variants.append((name, yahr_amd.make_opts(traverse=TR[tr], tuning=int(tun), spp=a.spp)))
+    parts = v.split(":")
+    name, tr, tun = parts[0], parts[1], parts[2]
+    frames = int(parts[3]) if len(parts) > 3 else 1
+    assert frames <= MAXF
+    variants.append((name, yahr_amd.make_opts(traverse=TR[tr], tuning=int(tun), spp=a.spp, frames=frames)))
 times = {n: [] for n, _ in variants}
 ref = None
 for r in range(a.rounds + 2):
@@ -43,9 +47,12 @@ for r in range(a.rounds + 2):
         e1.record(st)
         torch.cuda.synchronize()
         if r >= 2:
-            times[name].append(e0.elapsed_time(e1))
+            times[name].append(e0.elapsed_time(e1) / max(1, o.frames))
         if r == 0:
-            img = out.clone()
+            img = out[0].clone()
+            for f in range(1, max(1, o.frames)):
+                if not torch.equal(out[f].view(torch.int32), img.view(torch.int32)):
+                    print(f"WARNING: variant {name}: frame {f} differs from frame 0")
             if ref is None:
                 ref = img
             elif not torch.equal(img.view(torch.int32), ref.view(torch.int32)):
@@ -60,4 +67,4 @@ rays = s["primary_rays"] + s["reflection_rays"] + s["shadow_rays"]
 print(f"scene {a.scene} {scene.width}x{scene.height} spp {a.spp}: {rays} rays/frame")
 for name, _ in variants:
     t = sorted(times[name])
-    print(f"  {name:14s} min {t[0]:8.3f} ms  median {t[len(t) // 2]:8.3f} ms   {rays / t[0] / 1e3:9.1f} Mrays/s (at min)")
+    print(f"  {name:14s} min {t[0]:8.3f} ms/frame  median {t[len(t) // 2]:8.3f} ms/frame   {rays / t[0] / 1e3:9.1f} Mrays/s (at min)")

@@ -200,13 +200,15 @@ class Scene:
 
 
 def make_opts(spp=1, seed=0, traverse=TRAVERSE_AUTO, tiles=TILES_WAVE, n_batches=0, collect_stats=False,
-              n_shards=1, shard=0, strip_rows=8, tuning=0):
+              n_shards=1, shard=0, strip_rows=8, tuning=0, frames=1, frame_rows=0):
     o = RenderOpts()
     lib.yahr_default_opts(C.byref(o))
     o.spp, o.seed, o.traverse, o.tiles, o.n_batches = spp, seed, traverse, tiles, n_batches
     o.collect_stats = int(collect_stats)
     o.n_shards, o.shard, o.strip_rows = n_shards, shard, strip_rows
     o.tuning = tuning
+    o.frames = frames
+    o.frame_rows = frame_rows
     return o
 
 
@@ -236,6 +238,12 @@ class Context:
         o = opts if opts is not None else make_opts()
         check(lib.yahr_ctx_render(self._h, row0, row1, C.byref(o), C.c_void_p(d_ptr), C.c_void_p(stream)))
 
+    def set_cameras(self, cameras):
+        """cameras for frame batches: rows of (imW, imH, focal, look[3], up[3], pos[3]); None/[] clears them"""
+        cams = np.zeros((0, 12), dtype=np.float32) if cameras is None else \
+            np.ascontiguousarray(cameras, dtype=np.float32).reshape(-1, 12)
+        check(lib.yahr_ctx_set_cameras(self._h, cams.shape[0], _fptr(cams) if cams.shape[0] else None))
+
     def stats(self):
         st = Stats()
         check(lib.yahr_ctx_stats(self._h, C.byref(st)))
@@ -249,7 +257,8 @@ class Context:
             row1 = self.height
         rows = shard_rows(self.height, o.n_shards, o.shard, o.strip_rows) if o.n_shards > 1 else row1 - row0
         dev = torch.device("cuda", self.device)
-        out = torch.zeros((rows, self.width, 3), dtype=torch.float32, device=dev)
+        shape = (rows, self.width, 3) if o.frames <= 1 else (o.frames, rows, self.width, 3)
+        out = torch.zeros(shape, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             self.render_into(out.data_ptr(), row0, row1, o, torch.cuda.current_stream().cuda_stream)
         return out

@@ -56,7 +56,7 @@ class RenderOpts(C.Structure):
     _fields_ = [("spp", C.c_int32), ("seed", C.c_uint32), ("traverse", C.c_int32), ("tiles", C.c_int32),
                 ("n_batches", C.c_int32), ("collect_stats", C.c_int32),
                 ("n_shards", C.c_int32), ("shard", C.c_int32), ("strip_rows", C.c_int32),
-                ("tuning", C.c_int32), ("reserved", C.c_int32 * 6)]
+                ("tuning", C.c_int32), ("frames", C.c_int32), ("frame_rows", C.c_int32), ("reserved", C.c_int32 * 4)]
 
 
 class Stats(C.Structure):
@@ -101,6 +101,7 @@ SIGNATURES = {
     "yahr_shard_rows": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "yahr_shard_global_row": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "yahr_ctx_render": (C.c_int, [_VP, C.c_int32, C.c_int32, C.POINTER(RenderOpts), _VP, _VP]),
+    "yahr_ctx_set_cameras": (C.c_int, [_VP, C.c_int32, _F3]),
     "yahr_ctx_stats": (C.c_int, [_VP, C.POINTER(Stats)]),
     "yahr_ctx_trace": (C.c_int, [_VP, C.c_int32, _F3, C.c_int32, C.POINTER(C.c_int32), _F3]),
     "yahr_ctx_occluded": (C.c_int, [_VP, C.c_int32, _F3, C.c_int32, C.POINTER(C.c_int32)]),

@@ -56,6 +56,27 @@ YD bool slab_hit(V3 lo, V3 hi, V3 o, V3 inv, float tmax) {
   return !(tnear > tfar);
 }
 
+// The same predicate with hardware min/max (v_min_f32 / v_max_f32 / v_min3 / v_max3), valid when NO t0/t1
+// can be NaN.  Then hmin/hmax equal the mathematical min/max (up to the sign of a zero, which no comparison
+// sees), so the Boolean is identical to slab_hit's.  A NaN needs 0*inf or inf-inf: impossible when the box is
+// finite, the origin is finite and every reciprocal direction component is finite and non-zero -- the caller
+// checks exactly that (slab_safe) for every active lane before choosing this form.  A NaN tMax is harmless:
+// hmin(tMax, x) = x = v_min(tMax, x).
+YD bool slab_hit_fast(V3 lo, V3 hi, V3 o, V3 inv, float tmax) {
+  const float t0x = (lo.x - o.x) * inv.x, t1x = (hi.x - o.x) * inv.x;
+  const float t0y = (lo.y - o.y) * inv.y, t1y = (hi.y - o.y) * inv.y;
+  const float t0z = (lo.z - o.z) * inv.z, t1z = (hi.z - o.z) * inv.z;
+  const float tnear = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.0f));
+  const float tfar = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax));
+  return !(tnear > tfar);
+}
+YD bool finite_nonzero(float x) { const float a = fabsf(x); return a > 0.0f && a < __builtin_huge_valf(); }
+YD bool finite_f(float x) { return fabsf(x) < __builtin_huge_valf(); }
+YD bool slab_safe(V3 o, V3 inv) {
+  return finite_f(o.x) && finite_f(o.y) && finite_f(o.z) &&
+         finite_nonzero(inv.x) && finite_nonzero(inv.y) && finite_nonzero(inv.z);
+}
+
 // ---- Shapes.hs:36-59 collideTriangle, geometric part ---------------------------------------------
 // Returns the conjunction of every acceptance test that does not need the normals; the caller then
 // applies `u .* ns < 0` (Shapes.hs:57).  Short-circuit order does not matter: the tests are pure.

@@ -41,7 +41,7 @@ using namespace yd;
 
 // Tuning knobs (compile time).  YAHR_WAVES: waves per SIMD the register allocator must make room for.
 #ifndef YAHR_WAVES
-#define YAHR_WAVES 4
+#define YAHR_WAVES 5   // swept 3..8 on the pseudo-bunny: flat within 4 % (the kernel is critical-path bound), 5 best
 #endif
 #define YAHR_KERNEL_ATTR __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(YAHR_WAVES, 8)))
 
@@ -165,12 +165,11 @@ YD int wave_min_i32(int v) {
 // The successor in array order (i+1: always the next node after a leaf, and the left child of a hit
 // interior node) and a leaf's first primitive are requested before the slab test of the current node, so
 // that round trip overlaps the VALU work; only a skip needs a dependent load.
-template <bool STATS>
-YD void traverse_packet(const DScene &sc, bool active, bool any_hit, V3 o, V3 u, float tmax, Hit &hit, Counters &c) {
-  const V3 inv = v3(1.0f / u.x, 1.0f / u.y, 1.0f / u.z);
-  hit.prim = -1; hit.t = 0.0f; hit.b1 = 0.0f; hit.b2 = 0.0f;
+// FAST selects the hardware-min/max slab test (device_math.hpp: slab_hit_fast), legal for this traversal
+// when no lane can produce a NaN in it.
+template <bool STATS, bool FAST>
+YD void packet_loop(const DScene &sc, bool active, bool any_hit, V3 o, V3 u, V3 inv, float tmax, Hit &hit, Counters &c) {
   const int n = sc.n_nodes;
-  if (n == 0 || !__any(active)) return;
   int wake = active ? 0 : YD_DONE;
   int i = 0;                                           // wave-uniform: lives in an SGPR
   NodeRec cur = load_node(sc, 0);
@@ -181,7 +180,8 @@ YD void traverse_packet(const DScene &sc, bool active, bool any_hit, V3 o, V3 u,
     if (b >= 0) pcur = load_prim(sc, b);               // leaf: first primitive (padded array)
     const bool on = wake <= i;
     if (STATS) { c.box += on ? 1u : 0u; c.wave_nodes++; }
-    const bool h = slab_hit(xyz(cur.lo), xyz(cur.hi), o, inv, tmax) & on;   // branch-free, masked afterwards
+    const bool h = (FAST ? slab_hit_fast(xyz(cur.lo), xyz(cur.hi), o, inv, tmax)
+                         : slab_hit(xyz(cur.lo), xyz(cur.hi), o, inv, tmax)) & on;   // branch-free, masked afterwards
     const bool anyh = __any(h);
     int next = i + 1;
     if (b >= 0) {                                      // leaf (wave-uniform branch)
@@ -213,6 +213,17 @@ YD void traverse_packet(const DScene &sc, bool active, bool any_hit, V3 o, V3 u,
     if (next == i + 1) cur = nseq; else cur = load_node(sc, next);
     i = next;
   }
+}
+
+template <bool STATS>
+YD void traverse_packet(const DScene &sc, bool active, bool any_hit, V3 o, V3 u, float tmax, Hit &hit, Counters &c) {
+  const V3 inv = v3(1.0f / u.x, 1.0f / u.y, 1.0f / u.z);
+  hit.prim = -1; hit.t = 0.0f; hit.b1 = 0.0f; hit.b2 = 0.0f;
+  if (sc.n_nodes == 0 || !__any(active)) return;
+  // every node box finite (host check) and no active lane able to form 0*inf or inf-inf in the slab test?
+  const bool fast = sc.boxes_finite != 0 && !__any(active & !slab_safe(o, inv));
+  if (fast) packet_loop<STATS, true>(sc, active, any_hit, o, u, inv, tmax, hit, c);
+  else packet_loop<STATS, false>(sc, active, any_hit, o, u, inv, tmax, hit, c);
 }
 
 // ray_class: 0 primary, 1 shadow, 2 reflection
@@ -336,8 +347,7 @@ YD V3 radiance(const DScene &sc, bool valid, V3 ro, V3 rd, float *lds, int lane,
   return v;
 }
 
-YD void camera_ray(const DScene &sc, float fu, float fv, V3 &ro, V3 &rd) {   // Cameras.hs:83-86
-  const DCold *cold = cold_of(sc);
+YD void camera_ray(const DCold *cold, float fu, float fv, V3 &ro, V3 &rd) {   // Cameras.hs:83-86
   const V3 origin = v3(cold->origin[0], cold->origin[1], cold->origin[2]);
   const V3 direction = transform_point(cold->vtf, v3(fu, fv, cold->focal)) - origin;
   ro = origin; rd = norm(direction);
@@ -372,17 +382,24 @@ __global__ YAHR_KERNEL_ATTR void k_render(DScene sc, RParams rp, float *__restri
   Counters c = {};
   bool bad_mat = false;
   const unsigned long long t_start = STATS ? clock64() : 0ULL;
-  int tile = blockIdx.x;
+  // frame batch: the same tile of every frame of the batch sits next to each other in dispatch order
+  const int frame = rp.frames > 1 ? (int)(blockIdx.x % (unsigned)rp.frames) : 0;
+  int tile = rp.frames > 1 ? (int)(blockIdx.x / (unsigned)rp.frames) : (int)blockIdx.x;
   if (rp.tile_mode == 0 && rp.xcd_swizzle) {           // diagnostics: contiguous band of tiles per XCD
     const int per = (rp.n_tiles + 7) >> 3;
     tile = (tile & 7) * per + (tile >> 3);
   }
+  const DCold *cam = rp.cams ? rp.cams + frame : sc.cold;
+  out += (size_t)frame * rp.frame_stride;
   // NOTE: the ONLY global stores of this kernel come after the last traversal.  A store (or atomic) ahead of
   // a scene load makes that load "clobberable" for the compiler, which then refuses the scalar-load path and
   // silently turns the packet walker's node fetches into per-lane gathers (tests/test_isa.py guards this).
   int u, gv; size_t row; bool valid;
   if (rp.tile_mode == 0) {
-    const int ty = tile / rp.tiles_x, tx = tile - ty * rp.tiles_x;
+    int ty = tile / rp.tiles_x;
+    const int tx = tile - ty * rp.tiles_x;
+    // optional permutation of the tile rows (diagnostics; centre-rows-first measured slower than natural order)
+    if (rp.row_order && tile < rp.n_tiles) ty = rp.row_order[ty];
     u = tx * 8 + (lane & 7);
     const int lv = ty * 8 + (lane >> 3);
     // local row -> global image row (row sharding, include/yahr_hip.h yahr_render_opts)
@@ -405,7 +422,7 @@ __global__ YAHR_KERNEL_ATTR void k_render(DScene sc, RParams rp, float *__restri
     float du = 0.0f, dv = 0.0f;                        // spp == 1: the integer pixel corner (main.hs:73)
     if (rp.spp > 1) sample_offset(u, gv, s, rp.n_strata, rp.seed, du, dv);
     V3 ro, rd;
-    camera_ray(sc, (float)u + du, (float)gv + dv, ro, rd);
+    camera_ray(cam, (float)u + du, (float)gv + dv, ro, rd);
     const V3 v = radiance<MODE, STATS>(sc, valid, ro, rd, lds, lane, c, bad_mat);
     acc = (rp.spp > 1) ? acc + v : v;
   }
@@ -463,7 +480,7 @@ __global__ void k_camera_rays(DScene sc, int n, const float *__restrict__ uv, fl
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   V3 ro, rd;
-  camera_ray(sc, uv[2 * (size_t)i], uv[2 * (size_t)i + 1], ro, rd);
+  camera_ray(sc.cold, uv[2 * (size_t)i], uv[2 * (size_t)i + 1], ro, rd);
   float *p = rays + 7 * (size_t)i;
   p[0] = ro.x; p[1] = ro.y; p[2] = ro.z; p[3] = rd.x; p[4] = rd.y; p[5] = rd.z; p[6] = 1e6f;
 }

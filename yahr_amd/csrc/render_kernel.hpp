@@ -24,6 +24,7 @@ struct DScene {
   const DCold *cold;
   int n_nodes, n_prims, n_mats, n_lights;
   int depth;
+  int boxes_finite;        // every node box has finite lo <= hi: enables the NaN-free slab form
 };
 
 struct RParams {
@@ -35,7 +36,14 @@ struct RParams {
   int spp, n_strata; unsigned seed;
   int tile_mode;           // 0: 8x8 wave tiles, 1: reference squareBatches windows
   int xcd_swizzle;
-  const int4 *windows;     // tile_mode 1: {x0,y0,x1,y1} per batch
+  const int4 *windows;     // tile_mode 1: {x0,y0,x1,y1}, {p0,batch,0,0} per 64-pixel chunk
+  // frame batch: one launch renders `frames` frames; block b -> (tile b / frames, frame b % frames), so the
+  // same tile of all frames is adjacent in dispatch order.  Frame f writes at out + f * frame_stride floats
+  // and takes its camera from cams[f] (NULL: the scene camera for every frame).
+  int frames;
+  size_t frame_stride;
+  const DCold *cams;
+  const int *row_order;    // tile_mode 0: dispatch position -> tile row (centre rows first), or NULL = natural
 };
 
 enum { TRAV_LANE = 1, TRAV_PACKET = 2, TRAV_HYBRID = 3 };

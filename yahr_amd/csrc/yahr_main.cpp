@@ -69,6 +69,7 @@ int main(int argc, char **argv) {
 
   yahr_render_opts opts; yahr_default_opts(&opts);
   if (const char *e = std::getenv("YAHR_SPP")) { int s = std::atoi(e); if (s >= 1) opts.spp = s; }
+  if (const char *e = std::getenv("YAHR_STATS")) opts.collect_stats = std::atoi(e) != 0;
   const int n_batches = yahr_n_batches(threads, flat->width, flat->height);
   // main.hs:140-141 prints this line before the (lazy) render is forced
   std::printf("%d threads, %d batches, parallel %s\n", threads, n_batches, mode.c_str());
@@ -79,9 +80,11 @@ int main(int argc, char **argv) {
   int rc = yahr_render_multi(flat, n_dev, &opts, rgb.data(), &st);
   if (rc != YAHR_OK) { std::string e = yahr_last_error(); yahr_scene_free(hs); return die(e); }
   const double rays = (double)(st.primary_rays + st.reflection_rays + st.shadow_rays);
-  std::fprintf(stderr, "yahr-hip: %d x gfx950, %dx%d, %.3f ms kernel, %.1f Mrays/s, %.1f Mpixels/s\n", n_dev,
-               flat->width, flat->height, st.kernel_ms, st.kernel_ms > 0 ? rays / st.kernel_ms / 1e3 : 0.0,
-               st.kernel_ms > 0 ? (double)flat->width * flat->height / st.kernel_ms / 1e3 : 0.0);
+  std::fprintf(stderr, "yahr-hip: %d x gfx950, %dx%d, %.3f ms kernel, %.1f Mpixels/s", n_dev, flat->width, flat->height,
+               st.kernel_ms, st.kernel_ms > 0 ? (double)flat->width * flat->height / st.kernel_ms / 1e3 : 0.0);
+  if (opts.collect_stats)   // ray counts exist in the counted (slower) kernel build only: YAHR_STATS=1
+    std::fprintf(stderr, ", %.0f rays, %.1f Mrays/s", rays, st.kernel_ms > 0 ? rays / st.kernel_ms / 1e3 : 0.0);
+  std::fprintf(stderr, "\n");
 
   if (flat->width <= 0 || flat->height <= 0) { yahr_scene_free(hs); return die("image has zero size"); }
   if (ends_with(pos[1], ".ppm")) rc = yahr_write_ppm(pos[1].c_str(), rgb.data(), flat->width, flat->height);

@@ -4,8 +4,9 @@
 The reference parallelises over independent pixel tiles inside one process (main.hs:75-96).  Here the image
 is cut into strips of `strip_rows` rows dealt round-robin to the ranks (strip s -> rank s % world), every
 rank renders its strips with the scene replicated in its own HBM, and there is exactly ONE collective per
-frame: a gather of the float RGB strips to rank 0, which scatters them to their image rows
-(samplesToImage, main.hs:98-107) with a single index_copy.  No exchange step exists inside the frame.
+launch: a gather of the float RGB strips (of every frame of the launch's frame batch) to rank 0, which
+scatters them to their image rows (samplesToImage, main.hs:98-107) with a single index_copy.  No exchange
+step exists inside a frame.
 """
 import torch
 import torch.distributed as dist
@@ -14,10 +15,11 @@ from . import shard_global_rows, shard_rows
 
 
 class ShardPlan:
-    """Which rows each rank owns, and where they land in the final image."""
+    """Which rows each rank owns, and where they land in the final image(s)."""
 
-    def __init__(self, height, width, world, strip_rows=8, device="cpu"):
+    def __init__(self, height, width, world, strip_rows=8, device="cpu", frames=1):
         self.height, self.width, self.world, self.strip_rows = height, width, world, strip_rows
+        self.frames = frames
         self.device = torch.device(device)
         self.rows = [shard_rows(height, world, r, strip_rows) for r in range(world)]
         self.max_rows = max(self.rows) if self.rows else 0
@@ -30,36 +32,44 @@ class ShardPlan:
         self.dest = dest.reshape(-1).to(self.device)
 
     def buffers(self, rank):
-        """(local strip buffer, gather buffer [world, max_rows, w, 3] on rank 0, image buffer with a scratch row)"""
-        local = torch.zeros((self.max_rows, self.width, 3), dtype=torch.float32, device=self.device)
+        """(local strips [frames, max_rows, w, 3]; on rank 0 also the gather buffer [world, frames, max_rows, w, 3]
+        and the image buffer [frames, height + 1, w, 3] whose last row is scratch for padding rows)"""
+        f = self.frames
+        local = torch.zeros((f, self.max_rows, self.width, 3), dtype=torch.float32, device=self.device)
         if rank != 0:
             return local, None, None
-        gathered = torch.zeros((self.world, self.max_rows, self.width, 3), dtype=torch.float32, device=self.device)
-        image = torch.zeros((self.height + 1, self.width, 3), dtype=torch.float32, device=self.device)
+        gathered = torch.zeros((self.world, f, self.max_rows, self.width, 3), dtype=torch.float32, device=self.device)
+        image = torch.zeros((f, self.height + 1, self.width, 3), dtype=torch.float32, device=self.device)
         return local, gathered, image
 
     def assemble(self, parts, image=None):
-        """parts: [world, max_rows, width, 3] tensor (or a list of per-rank [>=rows[r], width, 3] tensors).
-        Returns the full image [height, width, 3] (a view of `image` when given)."""
+        """parts: [world, frames, max_rows, width, 3] (or [world, max_rows, width, 3], or a list of per-rank
+        [>= rows[r], width, 3] tensors for one frame).  Returns [frames, height, width, 3] (or [height, width, 3])."""
+        single = False
         if isinstance(parts, (list, tuple)):
-            buf = torch.zeros((self.world, self.max_rows, self.width, 3), dtype=parts[0].dtype, device=parts[0].device)
+            buf = torch.zeros((self.world, 1, self.max_rows, self.width, 3), dtype=parts[0].dtype, device=parts[0].device)
             for r, p in enumerate(parts):
-                buf[r, : self.rows[r]] = p[: self.rows[r]]
-            parts = buf
+                buf[r, 0, : self.rows[r]] = p[: self.rows[r]]
+            parts, single = buf, True
+        elif parts.dim() == 4:
+            parts, single = parts.unsqueeze(1), True
+        f = parts.shape[1]
         if image is None:
-            image = torch.empty((self.height + 1, self.width, 3), dtype=parts.dtype, device=parts.device)
-        image.index_copy_(0, self.dest.to(parts.device), parts.reshape(-1, self.width, 3))
-        return image[: self.height]
+            image = torch.empty((f, self.height + 1, self.width, 3), dtype=parts.dtype, device=parts.device)
+        src = parts.permute(1, 0, 2, 3, 4).reshape(f, self.world * self.max_rows, self.width, 3)
+        image.index_copy_(1, self.dest.to(parts.device), src)
+        out = image[:, : self.height]
+        return out[0] if single else out
 
 
 def render_sharded(render_fn, plan, rank, group=None, bufs=None):
-    """render_fn(shard, n_shards, strip_rows, out) renders this rank's strips into `out`
-    ([max_rows, width, 3]; rows beyond plan.rows[rank] are padding).  Returns the assembled image on rank 0,
-    None elsewhere.  One gather per call."""
+    """render_fn(shard, n_shards, strip_rows, out) renders this rank's strips of every frame of the batch into
+    `out` ([frames, max_rows, width, 3]; rows beyond plan.rows[rank] are padding).  Returns the assembled
+    images [frames, height, width, 3] on rank 0, None elsewhere.  One gather per call."""
     local, gathered, image = bufs if bufs is not None else plan.buffers(rank)
     render_fn(rank, plan.world, plan.strip_rows, local)
     if plan.world == 1:
-        return local[: plan.height]
+        return local[:, : plan.height]
     dist.gather(local, gather_list=[gathered[r] for r in range(plan.world)] if rank == 0 else None, dst=0, group=group)
     if rank != 0:
         return None

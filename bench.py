@@ -42,7 +42,13 @@ WORKLOADS = {
     "spheres": lambda: (scenes.spheres8(1920, 1080, depth=1),
                         "8 spheres + plane + 2 point lights, 1920x1080, 1 spp, Whitted depth 1, BVH 16 Midpoint"),
     "bunny_small": lambda: (scenes.pseudo_bunny(480, 270, depth=2), "pseudo-bunny 480x270 (smoke size)"),
+    # BASELINE.json configs[3] and [4]; spp > 1 and "stratified" are build extensions (sampler)
+    "bunny4k": lambda: (scenes.pseudo_bunny(3840, 2160, depth=4),
+                        "pseudo-bunny 3840x2160, 64 spp stratified, Whitted depth 4 (primary + 3 reflection segments)"),
+    "tris1m": lambda: (scenes.random_tris(1_000_000, 1920, 1080, depth=2, bvh_depth=20),
+                       "1M random triangles (splitmix64 seed 0x5EED), 1920x1080, 16 spp, Whitted depth 2, BVH 20 Midpoint"),
 }
+WORKLOAD_SPP = {"bunny4k": 64, "tris1m": 16}
 
 
 def algorithmic_bytes(st, n_lights, n_pixels):
@@ -52,13 +58,32 @@ def algorithmic_bytes(st, n_lights, n_pixels):
             + (32 + 24 * n_lights) * st["shaded_hits"] + 12 * n_pixels)
 
 
-def cpu_baseline(desc, cores, min_cpu_seconds=10.0):
+def cpu_baseline(desc, cores, spp=1, min_cpu_seconds=10.0):
     """The oracle (CPU restatement of the reference, kind "port": the Haskell reference cannot be built here)
-    timed on the host cores over the same workload: whole frames, repeated until ~min_cpu_seconds of CPU work."""
+    timed on the host cores over the same workload: whole frames, repeated until ~min_cpu_seconds of CPU work
+    (spp == 1), or a bounded sample of evenly spaced 8-row strips of one frame (supersampled workloads)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_py                      # the checker, timed beside the product; never part of the product path
     osc = oracle_py.OracleScene.from_desc(desc).build()
     reps, wall, rays, st = 0, 0.0, 0, None
+    if spp > 1:
+        w, h = osc.size()
+        strips = list(range(0, h - 7, 8))
+        order = [strips[(i * 37) % len(strips)] for i in range(len(strips))]      # spread over the image
+        prim, done = 0, 0
+        for r0 in order:
+            t0 = time.perf_counter()
+            _, st = osc.render_rows(r0, r0 + 8, spp=spp, seed=0, threads=cores)
+            wall += time.perf_counter() - t0
+            rays += st["primary_rays"] + st["reflection_rays"] + st["shadow_rays"]
+            prim += st["primary_rays"]
+            done += 1
+            if wall * cores >= min_cpu_seconds:
+                break
+        return dict(value=round(rays / wall / 1e6, 3), unit="Mrays/s", cores=cores, kind="port",
+                    sample=f"{done} strips of 8 rows (of {len(strips)}) spread over one frame at {spp} spp, render only, "
+                           f"{wall:.2f} s wall on {cores} threads (one thread per image row)",
+                    mpixels_per_s=round(prim / spp / wall / 1e6, 4)), None
     while wall * cores < min_cpu_seconds and reps < 50:
         t0 = time.perf_counter()
         _, st = osc.render(threads=cores)
@@ -126,9 +151,11 @@ def main():
     plan = ShardPlan(h, w, world, args.strip_rows, device=dev, frames=F)
     bufs = plan.buffers(rank)
     stream = torch.cuda.current_stream()
+    spp = WORKLOAD_SPP.get(args.workload, 1)
     o_run = yahr_amd.make_opts(traverse=trav, n_shards=world, shard=rank, strip_rows=args.strip_rows, frames=F,
-                               frame_rows=plan.max_rows)
-    o_stat = yahr_amd.make_opts(traverse=trav, n_shards=world, shard=rank, strip_rows=args.strip_rows, collect_stats=True)
+                               frame_rows=plan.max_rows, spp=spp)
+    o_stat = yahr_amd.make_opts(traverse=trav, n_shards=world, shard=rank, strip_rows=args.strip_rows, collect_stats=True,
+                                spp=spp)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_launches)]
     step_no = [-1]
 
@@ -189,12 +216,14 @@ def main():
                       else f"Mrays/s, {args.workload}",
             "value": round(rays_per_step * args.steps / elapsed / 1e6, 2),
             "unit": "Mrays/s",
-            "mpixels_per_s": round(primary_per_step * args.steps / elapsed / 1e6, 2),
+            "mpixels_per_s": round(primary_per_step / spp * args.steps / elapsed / 1e6, 2),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic (procedural pseudo-bunny: no bunny mesh ships with the reference)",
-            "config": {"workload": workload_name, "rays_per_frame": rays_per_step, "traverse": args.traverse,
+            "dtype": "f32",
+            "data": ("synthetic (procedural pseudo-bunny: no bunny mesh ships with the reference)"
+                     if args.workload.startswith("bunny") else "synthetic (generated scene, yahr_amd/scenes.py)"),
+            "config": {"workload": workload_name, "rays_per_frame": rays_per_step, "spp": spp, "traverse": args.traverse,
                        "sharding": f"{world} rank(s), strips of {args.strip_rows} rows round-robin, one gather to rank 0 per launch",
                        "frames_per_launch": F, "launches": n_launches,
                        "host_scene_build_s": round(build_s, 3)},
@@ -210,9 +239,10 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             cores = min(16, os.cpu_count() or 1)
-            cb, ost = cpu_baseline(desc, cores)
+            cb, ost = cpu_baseline(desc, cores, spp)
             out["cpu_baseline"] = cb
-            out["roofline"]["algorithmic_bytes_reference_order"] = algorithmic_bytes(ost, scene.n_lights, n_px)
+            if ost is not None:
+                out["roofline"]["algorithmic_bytes_reference_order"] = algorithmic_bytes(ost, scene.n_lights, n_px)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

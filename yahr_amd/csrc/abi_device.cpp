@@ -25,6 +25,7 @@ struct yahr_ctx {
   DCold cold_host{};
   DCold *d_cams = nullptr; int n_cams = 0;
   int *d_row_order = nullptr; int row_order_n = 0;
+  int auto_mode = TRAV_PACKET;
   unsigned long long *d_ctr = nullptr;
   int4 *d_windows = nullptr; int n_windows = 0, n_chunks = 0, windows_w = 0, windows_h = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -90,15 +91,24 @@ void camera_origin(const float tf[16], float origin[3]) {
   origin[0] = iw * tv[0]; origin[1] = iw * tv[1]; origin[2] = iw * tv[2];
 }
 
-int pick_mode(int traverse) {
+int pick_mode(int traverse, int auto_mode = TRAV_PACKET) {
   switch (traverse) {
     case YAHR_TRAVERSE_LANE: return TRAV_LANE;
     case YAHR_TRAVERSE_PACKET: return TRAV_PACKET;
-    case YAHR_TRAVERSE_HYBRID: return TRAV_HYBRID;
-    // YAHR_TRAVERSE_AUTO: the packet walker (measured on the pseudo-bunny, 1080p: packet 1.00 ms,
-    // hybrid 1.48 ms, lane 2.01 ms per frame)
-    default: return TRAV_PACKET;
+    case YAHR_TRAVERSE_HYBRID: return TRAV_ADAPTIVE;
+    default: return auto_mode;       // YAHR_TRAVERSE_AUTO: chosen per scene in yahr_ctx_create
   }
+}
+
+// AUTO policy.  Measured per frame at 1080p (ms: lane / packet / adaptive): pseudo-bunny (largest leaf 70)
+// 1.98 / 0.94 / 1.2-1.6; 200k random triangles (largest leaf 12) 5.7 / 4.5 / 4.2; 1M random triangles (largest
+// leaf 7) 11.1 / 26.5 / 10.6; 8 spheres 0.16 / 0.16 / 0.16.  Fat multi-leaves are where the packet's scalar
+// primitive broadcast shines and per-lane gathers crawl, so: largest leaf > 16 -> packet, else adaptive.
+int auto_mode_for(const yahr_scene *s) {
+  int32_t biggest = 0;
+  for (int32_t i = 0; i < s->n_nodes; ++i)
+    if (s->nodes[i].b >= 0 && s->nodes[i].a > biggest) biggest = s->nodes[i].a;
+  return biggest > 16 ? TRAV_PACKET : TRAV_ADAPTIVE;
 }
 
 }  // namespace
@@ -179,6 +189,7 @@ int yahr_ctx_create(const yahr_scene *s, int device, yahr_ctx **out) {
   d.cold = (const DCold *)c->d_cold;
   d.n_nodes = s->n_nodes; d.n_prims = s->n_prims; d.n_mats = s->n_mats; d.n_lights = s->n_lights;
   d.depth = s->depth;
+  c->auto_mode = auto_mode_for(s);
   d.boxes_finite = 1;
   for (int32_t i = 0; i < s->n_nodes && d.boxes_finite; ++i)
     for (int k = 0; k < 3; ++k)
@@ -289,7 +300,7 @@ int yahr_ctx_render(yahr_ctx *c, int32_t row0, int32_t row1, const yahr_render_o
     n_blocks *= rp.frames;
   }
   HIP_TRY(hipEventRecord(c->ev0, st));
-  HIP_TRY(yahr_dev::launch_render(c->ds, rp, pick_mode(o.traverse), n_blocks, d_rgb, c->d_ctr, o.collect_stats != 0, st));
+  HIP_TRY(yahr_dev::launch_render(c->ds, rp, pick_mode(o.traverse, c->auto_mode), n_blocks, d_rgb, c->d_ctr, o.collect_stats != 0, st));
   HIP_TRY(hipEventRecord(c->ev1, st));
   c->timed = true;
   return YAHR_OK;
@@ -352,7 +363,7 @@ static int ray_query(yahr_ctx *c, int32_t n, const float *rays, int which, int t
   float *d_rays = nullptr; int *d_i = nullptr; float *d_f = nullptr;
   HIP_TRY(hipMalloc((void **)&d_rays, sizeof(float) * 7 * (size_t)n));
   HIP_TRY(hipMemcpy(d_rays, rays, sizeof(float) * 7 * (size_t)n, hipMemcpyHostToDevice));
-  int mode = pick_mode(traverse);
+  int mode = pick_mode(traverse, c->auto_mode);
   int rc = YAHR_OK;
   if (which == 2) {
     HIP_TRY(hipMalloc((void **)&d_f, sizeof(float) * 3 * (size_t)n));
@@ -360,7 +371,7 @@ static int ray_query(yahr_ctx *c, int32_t n, const float *rays, int which, int t
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(fout, d_f, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost));
   } else {
-    if (mode == TRAV_HYBRID) mode = TRAV_PACKET;
+    if (mode == TRAV_ADAPTIVE) mode = TRAV_PACKET;
     HIP_TRY(hipMalloc((void **)&d_i, sizeof(int) * (size_t)n));
     HIP_TRY(hipMalloc((void **)&d_f, sizeof(float) * (size_t)n));
     HIP_TRY(yahr_dev::launch_trace(c->ds, mode, n, d_rays, which == 1, d_i, d_f, nullptr));

@@ -128,12 +128,10 @@ YD bool test_prim_packet(const DScene &sc, int idx, const PrimRec &p, bool live,
 }
 
 // ---- lane walker --------------------------------------------------------------------------------
+// continues a traversal from per-lane node index i (>= n: nothing left) with the lane's current tmax / hit
 template <bool STATS>
-YD void traverse_lane(const DScene &sc, bool active, bool any_hit, V3 o, V3 u, float tmax, Hit &hit, Counters &c) {
-  const V3 inv = v3(1.0f / u.x, 1.0f / u.y, 1.0f / u.z);
-  hit.prim = -1; hit.t = 0.0f; hit.b1 = 0.0f; hit.b2 = 0.0f;
+YD void lane_loop(const DScene &sc, int i, bool any_hit, V3 o, V3 u, V3 inv, float tmax, Hit &hit, Counters &c) {
   const int n = sc.n_nodes;
-  int i = active ? 0 : n;
   while (i < n) {
     const NodeRec nd = load_node(sc, i);
     const int a = __float_as_int(nd.lo.w), b = __float_as_int(nd.hi.w);
@@ -152,8 +150,27 @@ YD void traverse_lane(const DScene &sc, bool active, bool any_hit, V3 o, V3 u, f
   }
 }
 
+template <bool STATS>
+YD void traverse_lane(const DScene &sc, bool active, bool any_hit, V3 o, V3 u, float tmax, Hit &hit, Counters &c) {
+  const V3 inv = v3(1.0f / u.x, 1.0f / u.y, 1.0f / u.z);
+  hit.prim = -1; hit.t = 0.0f; hit.b1 = 0.0f; hit.b2 = 0.0f;
+  lane_loop<STATS>(sc, active ? 0 : sc.n_nodes, any_hit, o, u, inv, tmax, hit, c);
+}
+
 // ---- packet walker ------------------------------------------------------------------------------
 #define YD_DONE 0x7fffffff
+// adaptive hand-off: every YD_WINDOW node steps the wave looks at how many lane-steps were useful; below
+// YD_MIN_ACTIVE (of 64) on average the rays have diverged and each lane finishes on its own (lane walker).
+// Pays on thin-leaf trees (1M random triangles: packet 26.5 ms, lane 11.1, adaptive 10.6 per frame); on trees
+// with fat multi-leaves the lane walker is hopeless (70 gathers per lane per leaf) and the hand-off only
+// loses (pseudo-bunny 0.94 -> 1.2-1.6 ms whatever the window/threshold), so AUTO chooses per scene on the
+// host: yahr_ctx_create, by the largest leaf.
+#ifndef YD_WINDOW
+#define YD_WINDOW 32
+#endif
+#ifndef YD_MIN_ACTIVE
+#define YD_MIN_ACTIVE 14
+#endif
 
 YD int wave_min_i32(int v) {
 #pragma unroll
@@ -167,18 +184,30 @@ YD int wave_min_i32(int v) {
 // that round trip overlaps the VALU work; only a skip needs a dependent load.
 // FAST selects the hardware-min/max slab test (device_math.hpp: slab_hit_fast), legal for this traversal
 // when no lane can produce a NaN in it.
-template <bool STATS, bool FAST>
-YD void packet_loop(const DScene &sc, bool active, bool any_hit, V3 o, V3 u, V3 inv, float tmax, Hit &hit, Counters &c) {
+// Returns n when the traversal is complete, or (ADAPT only) the node index at which the wave gave up being a
+// packet: lane l then continues at max(i, wake_l) with its tmax / hit (outputs), see traverse_packet.
+template <bool STATS, bool FAST, bool ADAPT>
+YD int packet_loop(const DScene &sc, bool active, bool any_hit, V3 o, V3 u, V3 inv, float &tmax, Hit &hit, int &wake,
+                   Counters &c) {
   const int n = sc.n_nodes;
-  int wake = active ? 0 : YD_DONE;
+  wake = active ? 0 : YD_DONE;
   int i = 0;                                           // wave-uniform: lives in an SGPR
+  int window = YD_WINDOW, useful = 0;                  // wave-uniform
   NodeRec cur = load_node(sc, 0);
   for (;;) {
+    if (ADAPT) {
+      if (window == 0) {
+        if (useful < YD_WINDOW * YD_MIN_ACTIVE) return i;
+        window = YD_WINDOW; useful = 0;
+      }
+      --window;
+    }
     const int a = __float_as_int(cur.lo.w), b = __float_as_int(cur.hi.w);
     const NodeRec nseq = load_node(sc, i + 1);         // padded array: in bounds even for the last node
     PrimRec pcur;
     if (b >= 0) pcur = load_prim(sc, b);               // leaf: first primitive (padded array)
     const bool on = wake <= i;
+    if (ADAPT) useful += (int)lanes(on);
     if (STATS) { c.box += on ? 1u : 0u; c.wave_nodes++; }
     const bool h = (FAST ? slab_hit_fast(xyz(cur.lo), xyz(cur.hi), o, inv, tmax)
                          : slab_hit(xyz(cur.lo), xyz(cur.hi), o, inv, tmax)) & on;   // branch-free, masked afterwards
@@ -200,7 +229,7 @@ YD void packet_loop(const DScene &sc, bool active, bool any_hit, V3 o, V3 u, V3 
             // next node any lane still needs; readfirstlane tells the compiler the minimum is wave-uniform
             // (otherwise the loop exit looks divergent and every node load degrades to a per-lane gather)
             const int m = __builtin_amdgcn_readfirstlane(wave_min_i32(wake));
-            if (m == YD_DONE) break;
+            if (m == YD_DONE) return n;
             if (m > next) next = m;
           }
         }
@@ -209,32 +238,36 @@ YD void packet_loop(const DScene &sc, bool active, bool any_hit, V3 o, V3 u, V3 
       wake = (on & !h) ? a : wake;
       next = anyh ? i + 1 : a;
     }
-    if (next >= n) break;
+    if (next >= n) return n;
     if (next == i + 1) cur = nseq; else cur = load_node(sc, next);
     i = next;
   }
 }
 
-template <bool STATS>
+// ADAPT: packet while the rays stay coherent, then every lane on its own.  Both halves perform, per ray, the
+// reference's tests in the reference's order, so where the hand-off happens cannot change a result.
+template <bool STATS, bool ADAPT>
 YD void traverse_packet(const DScene &sc, bool active, bool any_hit, V3 o, V3 u, float tmax, Hit &hit, Counters &c) {
   const V3 inv = v3(1.0f / u.x, 1.0f / u.y, 1.0f / u.z);
   hit.prim = -1; hit.t = 0.0f; hit.b1 = 0.0f; hit.b2 = 0.0f;
-  if (sc.n_nodes == 0 || !__any(active)) return;
+  const int n = sc.n_nodes;
+  if (n == 0 || !__any(active)) return;
   // every node box finite (host check) and no active lane able to form 0*inf or inf-inf in the slab test?
   const bool fast = sc.boxes_finite != 0 && !__any(active & !slab_safe(o, inv));
-  if (fast) packet_loop<STATS, true>(sc, active, any_hit, o, u, inv, tmax, hit, c);
-  else packet_loop<STATS, false>(sc, active, any_hit, o, u, inv, tmax, hit, c);
+  int wake, i;
+  if (fast) i = packet_loop<STATS, true, ADAPT>(sc, active, any_hit, o, u, inv, tmax, hit, wake, c);
+  else i = packet_loop<STATS, false, ADAPT>(sc, active, any_hit, o, u, inv, tmax, hit, wake, c);
+  if (ADAPT && i < n) {
+    // a lane that already has its first hit in any-hit mode is parked at YD_DONE >= n
+    lane_loop<STATS>(sc, wake > i ? wake : i, any_hit, o, u, inv, tmax, hit, c);
+  }
 }
 
-// ray_class: 0 primary, 1 shadow, 2 reflection
 template <int MODE, bool STATS>
-YD void traverse(const DScene &sc, bool active, bool any_hit, V3 o, V3 u, float tmax, Hit &hit, Counters &c, int ray_class) {
+YD void traverse(const DScene &sc, bool active, bool any_hit, V3 o, V3 u, float tmax, Hit &hit, Counters &c) {
   if (MODE == TRAV_LANE) traverse_lane<STATS>(sc, active, any_hit, o, u, tmax, hit, c);
-  else if (MODE == TRAV_PACKET) traverse_packet<STATS>(sc, active, any_hit, o, u, tmax, hit, c);
-  else {  // hybrid: coherent ray classes as packets, reflection rays per lane
-    if (ray_class == 2) traverse_lane<STATS>(sc, active, any_hit, o, u, tmax, hit, c);
-    else traverse_packet<STATS>(sc, active, any_hit, o, u, tmax, hit, c);
-  }
+  else if (MODE == TRAV_PACKET) traverse_packet<STATS, false>(sc, active, any_hit, o, u, tmax, hit, c);
+  else traverse_packet<STATS, true>(sc, active, any_hit, o, u, tmax, hit, c);     // TRAV_ADAPTIVE
 }
 
 // ---- shading --------------------------------------------------------------------------------------
@@ -314,7 +347,7 @@ YD V3 radiance(const DScene &sc, bool valid, V3 ro, V3 rd, float *lds, int lane,
       if (STATS) c.shadow += lanes(active);
     }
     Hit hit;
-    traverse<MODE, STATS>(sc, active, phase != 0, qo, qd, qt, hit, c, phase != 0 ? 1 : (k == 0 ? 0 : 2));
+    traverse<MODE, STATS>(sc, active, phase != 0, qo, qd, qt, hit, c);
     if (phase == 0) {
       alive = alive && hit.prim >= 0;
       if (STATS) c.shaded += lanes(alive);
@@ -452,7 +485,7 @@ __global__ __launch_bounds__(64) void k_trace(DScene sc, int n, const float *__r
   V3 o = vof(0.0f), d = v3(0, 0, 1); float tmax = 0.0f;
   if (valid) { const float *p = rays + 7 * (size_t)i; o = v3(p[0], p[1], p[2]); d = v3(p[3], p[4], p[5]); tmax = p[6]; }
   Hit h; Counters c = {};
-  traverse<MODE, false>(sc, valid, any_hit != 0, o, d, tmax, h, c, any_hit ? 1 : 0);
+  traverse<MODE, false>(sc, valid, any_hit != 0, o, d, tmax, h, c);
   if (valid) {
     prim_out[i] = h.prim >= 0 ? __float_as_int(sc.prims[3 * (size_t)h.prim + 2].w) : -1;
     if (t_out) t_out[i] = h.t;
@@ -502,7 +535,7 @@ hipError_t launch_render(const DScene &sc, const RParams &rp, int mode, int n_bl
   switch (mode) {
     case TRAV_LANE: return launch_render_mode<TRAV_LANE>(sc, rp, n_blocks, lds_bytes, out, ctr, stats, st);
     case TRAV_PACKET: return launch_render_mode<TRAV_PACKET>(sc, rp, n_blocks, lds_bytes, out, ctr, stats, st);
-    default: return launch_render_mode<TRAV_HYBRID>(sc, rp, n_blocks, lds_bytes, out, ctr, stats, st);
+    default: return launch_render_mode<TRAV_ADAPTIVE>(sc, rp, n_blocks, lds_bytes, out, ctr, stats, st);
   }
 }
 
@@ -520,7 +553,7 @@ hipError_t launch_radiance(const DScene &sc, int mode, int n, const float *rays,
   const size_t lds_bytes = (size_t)(sc.depth > 0 ? sc.depth : 1) * 6 * 64 * sizeof(float);
   if (mode == TRAV_LANE) hipLaunchKernelGGL((k_radiance<TRAV_LANE>), dim3(nb), dim3(64), lds_bytes, st, sc, n, rays, rgb, ctr);
   else if (mode == TRAV_PACKET) hipLaunchKernelGGL((k_radiance<TRAV_PACKET>), dim3(nb), dim3(64), lds_bytes, st, sc, n, rays, rgb, ctr);
-  else hipLaunchKernelGGL((k_radiance<TRAV_HYBRID>), dim3(nb), dim3(64), lds_bytes, st, sc, n, rays, rgb, ctr);
+  else hipLaunchKernelGGL((k_radiance<TRAV_ADAPTIVE>), dim3(nb), dim3(64), lds_bytes, st, sc, n, rays, rgb, ctr);
   return hipGetLastError();
 }
 

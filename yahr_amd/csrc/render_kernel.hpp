@@ -46,7 +46,7 @@ struct RParams {
   const int *row_order;    // tile_mode 0: dispatch position -> tile row (centre rows first), or NULL = natural
 };
 
-enum { TRAV_LANE = 1, TRAV_PACKET = 2, TRAV_HYBRID = 3 };
+enum { TRAV_LANE = 1, TRAV_PACKET = 2, TRAV_ADAPTIVE = 3 };
 
 enum { CTR_PRIMARY = 0, CTR_REFLECTION, CTR_SHADOW, CTR_SHADED, CTR_BAD_MAT,
        CTR_BOX, CTR_TRI, CTR_SPH, CTR_WAVE_NODES, CTR_WAVE_PRIMS, CTR_COUNT,

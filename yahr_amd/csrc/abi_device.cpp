@@ -53,6 +53,10 @@ int check_scene(const yahr_scene *s) {
   if ((s->n_nodes && !s->nodes) || (s->n_prims && (!s->prims || !s->normals)) || (s->n_mats && !s->mats) || (s->n_lights && !s->lights)) {
     set_error("null array in yahr_scene"); return YAHR_E_ARG;
   }
+  // the kernel addresses records with 32-bit byte offsets
+  if ((uint64_t)(s->n_nodes + 1) * sizeof(yahr_node) > 0xffffffffULL || (uint64_t)(s->n_prims + 1) * sizeof(yahr_prim) > 0xffffffffULL) {
+    set_error("scene too large: node or primitive array exceeds 4 GiB"); return YAHR_E_ARG;
+  }
   // The kernel trusts the topology: validate it here so a malformed scene cannot fault the GPU.
   for (int32_t i = 0; i < s->n_nodes; ++i) {
     const yahr_node &nd = s->nodes[i];

@@ -62,12 +62,33 @@ YD V3 ld3(const float4 *p) { float4 v = *p; return v3(v.x, v.y, v.z); }
 
 struct NodeRec { float4 lo, hi; };            // yahr_node as two 16-byte words
 struct PrimRec { float4 r0, r1, r2; };        // yahr_prim as three 16-byte words
+// record fetches use 32-bit BYTE offsets (one shift or multiply instead of 64-bit index arithmetic; the host
+// refuses scenes whose node or primitive array would not fit in 4 GiB)
+#ifndef YAHR_OFF32
+#define YAHR_OFF32 1
+#endif
 YD NodeRec load_node(const DScene &sc, int i) {
-  NodeRec n; n.lo = sc.nodes[2 * (size_t)i]; n.hi = sc.nodes[2 * (size_t)i + 1]; return n;
+#if YAHR_OFF32
+  const float4 *q = (const float4 *)((const char *)sc.nodes + ((unsigned)i << 5));
+#else
+  const float4 *q = sc.nodes + 2 * (size_t)i;
+#endif
+  NodeRec n; n.lo = q[0]; n.hi = q[1]; return n;
 }
 YD PrimRec load_prim(const DScene &sc, int i) {
-  PrimRec p; const float4 *pr = sc.prims + 3 * (size_t)i; p.r0 = pr[0]; p.r1 = pr[1]; p.r2 = pr[2]; return p;
+#if YAHR_OFF32
+  const float4 *pr = (const float4 *)((const char *)sc.prims + (unsigned)i * 48u);
+#else
+  const float4 *pr = sc.prims + 3 * (size_t)i;
+#endif
+  PrimRec p; p.r0 = pr[0]; p.r1 = pr[1]; p.r2 = pr[2]; return p;
 }
+// wave-uniform "any lane": compare the ballot itself (HIP's __any() goes through an integer VGPR)
+#if YAHR_OFF32
+YD bool wany(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ULL; }
+#else
+YD bool wany(bool p) { return __any(p); }
+#endif
 
 // Cold scene block.  (Do NOT launder this pointer through an `asm volatile`: the statement counts as a
 // possible clobber and the compiler then refuses scalar loads for every scene array -- measured.)
@@ -77,7 +98,7 @@ YD const DCold *cold_of(const DScene &sc) { return sc.cold; }
 // second half of collideTriangle for a lane that passed every geometric test: interpolated normal and
 // back-face cull (Shapes.hs:47-48,57); updates (hit, tmax) on accept
 YD bool tri_accept(const DScene &sc, int idx, V3 u, float t, float b1, float b2, float &tmax, Hit &hit) {
-  const float4 *nr = sc.normals + 3 * (size_t)idx;
+  const float4 *nr = (const float4 *)((const char *)sc.normals + (unsigned)idx * 48u);
   const V3 ns = tri_shading_normal(b1, b2, ld3(nr), ld3(nr + 1), ld3(nr + 2));
   if (!(dot(u, ns) < 0.0f)) return false;
   hit.prim = idx; hit.t = t; hit.b1 = b1; hit.b2 = b2; tmax = t;
@@ -110,7 +131,7 @@ YD bool test_prim_packet(const DScene &sc, int idx, const PrimRec &p, bool live,
     if (STATS) c.tri += live ? 1u : 0u;
     V3 s; float inv, b1;
     const bool p1 = tri_stage1(xyz(p.r0), xyz(p.r1), xyz(p.r2), o, u, s, inv, b1) & live;
-    if (__any(p1)) {
+    if (wany(p1)) {
       float t, b2;
       const bool p2 = tri_stage2(xyz(p.r1), xyz(p.r2), s, u, inv, b1, tmax, t, b2) & p1;
       if (p2) got = tri_accept(sc, idx, u, t, b1, b2, tmax, hit);
@@ -209,9 +230,11 @@ YD int packet_loop(const DScene &sc, bool active, bool any_hit, V3 o, V3 u, V3 i
     const bool on = wake <= i;
     if (ADAPT) useful += (int)lanes(on);
     if (STATS) { c.box += on ? 1u : 0u; c.wave_nodes++; }
-    const bool h = (FAST ? slab_hit_fast(xyz(cur.lo), xyz(cur.hi), o, inv, tmax)
-                         : slab_hit(xyz(cur.lo), xyz(cur.hi), o, inv, tmax)) & on;   // branch-free, masked afterwards
-    const bool anyh = __any(h);
+    // branch-free for all lanes, masked afterwards; "any lane" is decided on the two compare masks themselves
+    const bool hs = FAST ? slab_hit_fast(xyz(cur.lo), xyz(cur.hi), o, inv, tmax)
+                         : slab_hit(xyz(cur.lo), xyz(cur.hi), o, inv, tmax);
+    const bool h = hs & on;
+    const bool anyh = (__builtin_amdgcn_ballot_w64(hs) & __builtin_amdgcn_ballot_w64(on)) != 0ULL;
     int next = i + 1;
     if (b >= 0) {                                      // leaf (wave-uniform branch)
       if (anyh) {
@@ -225,7 +248,7 @@ YD int packet_loop(const DScene &sc, bool active, bool any_hit, V3 o, V3 u, V3 i
         }
         if (any_hit) {
           if (got) wake = YD_DONE;
-          if (__any(got)) {
+          if (wany(got)) {
             // next node any lane still needs; readfirstlane tells the compiler the minimum is wave-uniform
             // (otherwise the loop exit looks divergent and every node load degrades to a per-lane gather)
             const int m = __builtin_amdgcn_readfirstlane(wave_min_i32(wake));
@@ -251,9 +274,9 @@ YD void traverse_packet(const DScene &sc, bool active, bool any_hit, V3 o, V3 u,
   const V3 inv = v3(1.0f / u.x, 1.0f / u.y, 1.0f / u.z);
   hit.prim = -1; hit.t = 0.0f; hit.b1 = 0.0f; hit.b2 = 0.0f;
   const int n = sc.n_nodes;
-  if (n == 0 || !__any(active)) return;
+  if (n == 0 || !wany(active)) return;
   // every node box finite (host check) and no active lane able to form 0*inf or inf-inf in the slab test?
-  const bool fast = sc.boxes_finite != 0 && !__any(active & !slab_safe(o, inv));
+  const bool fast = sc.boxes_finite != 0 && !wany(active & !slab_safe(o, inv));
   int wake, i;
   if (fast) i = packet_loop<STATS, true, ADAPT>(sc, active, any_hit, o, u, inv, tmax, hit, wake, c);
   else i = packet_loop<STATS, false, ADAPT>(sc, active, any_hit, o, u, inv, tmax, hit, wake, c);
@@ -276,7 +299,7 @@ YD int surface_of(const DScene &sc, V3 ro, V3 rd, const Hit &hit, V3 &x, V3 &n, 
   const PrimRec p = load_prim(sc, hit.prim);
   x = ro + scale(hit.t, rd);                                          // dgPoint / rayAt
   if (__float_as_int(p.r1.w) == 0) {
-    const float4 *nr = sc.normals + 3 * (size_t)hit.prim;
+    const float4 *nr = (const float4 *)((const char *)sc.normals + (unsigned)hit.prim * 48u);
     V3 ns = tri_shading_normal(hit.b1, hit.b2, ld3(nr), ld3(nr + 1), ld3(nr + 2));
     V3 ss = norm(xyz(p.r2));                                          // norm e2
     V3 ts = norm(cross(ss, ns));
@@ -323,7 +346,7 @@ YD V3 radiance(const DScene &sc, bool valid, V3 ro, V3 rd, float *lds, int lane,
     const int k = step / per, phase = step - k * per;
     V3 qo = ro, qd = rd; float qt = 1e6f; bool active;
     if (phase == 0) {
-      if (!__any(alive)) break;
+      if (!wany(alive)) break;
       if (STATS) { if (k == 0) c.primary += lanes(alive); else c.reflection += lanes(alive); }
       active = alive;
       direct = vof(0.0f);

@@ -31,7 +31,7 @@ import torch.distributed as dist
 
 import yahr_amd
 from yahr_amd import scenes
-from yahr_amd.dist import ShardPlan, render_sharded
+from yahr_amd.dist import ShardPipeline, ShardPlan
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling ~6290 GB/s
 
@@ -119,11 +119,15 @@ def main():
     ap.add_argument("--strip-rows", type=int, default=8)
     ap.add_argument("--frames-per-launch", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="finish gather + assembly of a launch before the next render starts (diagnostics)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "YAHR_BENCH_FORCE_DEVICE" in os.environ:       # rehearsal of N ranks on one GPU (diagnostics only)
+        local_rank = int(os.environ["YAHR_BENCH_FORCE_DEVICE"])
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
@@ -149,7 +153,9 @@ def main():
         F -= 1
     n_launches = args.steps // F
     plan = ShardPlan(h, w, world, args.strip_rows, device=dev, frames=F)
-    bufs = plan.buffers(rank)
+    # double-buffered: gather + assembly of launch i overlap the render of launch i+1 (yahr_amd/dist.py)
+    pipe = ShardPipeline(plan, rank)
+    bufs = pipe.slots[0]
     stream = torch.cuda.current_stream()
     spp = WORKLOAD_SPP.get(args.workload, 1)
     o_run = yahr_amd.make_opts(traverse=trav, n_shards=world, shard=rank, strip_rows=args.strip_rows, frames=F,
@@ -180,7 +186,8 @@ def main():
 
     # ---- warmup (>= W frames), then EXACTLY K timed steps (= K/F launches) bracketed by barrier + synchronize
     for _ in range((args.warmup + F - 1) // F):
-        render_sharded(render_fn, plan, rank, bufs=bufs)
+        pipe.submit(render_fn)
+    pipe.drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -189,7 +196,10 @@ def main():
     img = None
     for i in range(n_launches):
         step_no[0] = i
-        img = render_sharded(render_fn, plan, rank, bufs=bufs)
+        pipe.submit(render_fn)
+        if args.no_overlap:
+            pipe.drain()
+    img = pipe.drain()                      # every launch rendered, gathered and assembled before the clock stops
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -224,7 +234,8 @@ def main():
             "data": ("synthetic (procedural pseudo-bunny: no bunny mesh ships with the reference)"
                      if args.workload.startswith("bunny") else "synthetic (generated scene, yahr_amd/scenes.py)"),
             "config": {"workload": workload_name, "rays_per_frame": rays_per_step, "spp": spp, "traverse": args.traverse,
-                       "sharding": f"{world} rank(s), strips of {args.strip_rows} rows round-robin, one gather to rank 0 per launch",
+                       "sharding": f"{world} rank(s), strips of {args.strip_rows} rows round-robin, one gather to rank 0 per "
+                                   "launch, gather+assembly of launch i overlapped with the render of launch i+1",
                        "frames_per_launch": F, "launches": n_launches,
                        "host_scene_build_s": round(build_s, 3)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -70,3 +70,61 @@ def test_plan_single_rank_is_identity():
     assert torch.equal(plan.assemble([x]), x)
     img = render_sharded(lambda s, n, st, out: out.copy_(x.unsqueeze(0)), plan, 0)
     assert torch.equal(img[0], x)
+
+
+def _pipe_worker(rank, world, port, w, h, strip, frames, n_launches, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from yahr_amd import shard_global_rows
+        from yahr_amd.dist import ShardPipeline
+        plan = ShardPlan(h, w, world, strip, frames=frames)
+        pipe = ShardPipeline(plan, rank)
+        seen = {}
+        pipe.on_assembled = lambda i, imgs: seen.__setitem__(i, imgs.clone())
+        launch = [0]
+
+        def render_fn(shard, n_shards, strip_rows, out):
+            # synthetic "render": pixel value encodes (launch, frame, global row, column) -- any mix-up of slots,
+            # ranks, frames or rows shows up in the assembled image
+            rows = torch.from_numpy(shard_global_rows(h, n_shards, shard, strip_rows)).float()
+            out.zero_()
+            for f in range(frames):
+                val = launch[0] * 1000.0 + f * 100.0 + rows[:, None] + torch.arange(w).float()[None, :] / 64.0
+                out[f, : len(rows)] = val[:, :, None].expand(-1, -1, 3)
+        for i in range(n_launches):
+            launch[0] = i
+            pipe.submit(render_fn)
+        last = pipe.drain()
+        if rank == 0:
+            assert sorted(seen) == list(range(n_launches)), sorted(seen)
+            rows = torch.arange(h).float()
+            for i in range(n_launches):
+                for f in range(frames):
+                    want = i * 1000.0 + f * 100.0 + rows[:, None] + torch.arange(w).float()[None, :] / 64.0
+                    assert torch.equal(seen[i][f, :, :, 0], want), (i, f)
+            assert torch.equal(last, seen[n_launches - 1])
+            open(out_path, "w").write("ok")
+        else:
+            assert last is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,frames,n_launches", [(2, 2, 5), (3, 1, 4), (2, 3, 1)])
+def test_overlapped_pipeline_gloo(tmp_path, world, frames, n_launches):
+    out = str(tmp_path / "ok.txt")
+    mp.spawn(_pipe_worker, args=(world, _free_port(), 33, 29, 4, frames, n_launches, out), nprocs=world, join=True)
+    assert open(out).read() == "ok"
+
+
+def test_pipeline_single_rank():
+    from yahr_amd.dist import ShardPipeline
+    plan = ShardPlan(11, 4, 1, 8, frames=2)
+    pipe = ShardPipeline(plan, 0)
+    for i in range(3):
+        pipe.submit(lambda s, n, st, out, i=i: out.fill_(float(i)))
+    img = pipe.drain()
+    assert img.shape == (2, 11, 4, 3) and float(img.min()) == 2.0 == float(img.max())

@@ -7,6 +7,10 @@ rank renders its strips with the scene replicated in its own HBM, and there is e
 launch: a gather of the float RGB strips (of every frame of the launch's frame batch) to rank 0, which
 scatters them to their image rows (samplesToImage, main.hs:98-107) with a single index_copy.  No exchange
 step exists inside a frame.
+
+`ShardPipeline` double-buffers that: the gather (RCCL's own stream) and the assembly (a side stream on
+rank 0) of launch i run while launch i+1 renders, so a steady stream of launches costs
+max(render, gather + assemble) instead of their sum.
 """
 import torch
 import torch.distributed as dist
@@ -63,9 +67,9 @@ class ShardPlan:
 
 
 def render_sharded(render_fn, plan, rank, group=None, bufs=None):
-    """render_fn(shard, n_shards, strip_rows, out) renders this rank's strips of every frame of the batch into
-    `out` ([frames, max_rows, width, 3]; rows beyond plan.rows[rank] are padding).  Returns the assembled
-    images [frames, height, width, 3] on rank 0, None elsewhere.  One gather per call."""
+    """Unpipelined form: render_fn(shard, n_shards, strip_rows, out) renders this rank's strips of every frame of
+    the batch into `out` ([frames, max_rows, width, 3]; rows beyond plan.rows[rank] are padding).  Returns the
+    assembled images [frames, height, width, 3] on rank 0, None elsewhere.  One gather per call."""
     local, gathered, image = bufs if bufs is not None else plan.buffers(rank)
     render_fn(rank, plan.world, plan.strip_rows, local)
     if plan.world == 1:
@@ -74,3 +78,75 @@ def render_sharded(render_fn, plan, rank, group=None, bufs=None):
     if rank != 0:
         return None
     return plan.assemble(gathered, image)
+
+
+class ShardPipeline:
+    """Double-buffered launches: submit() renders launch i and starts its gather asynchronously; the gather and
+    (on rank 0) the assembly of launch i complete while launch i+1 renders.  drain() finishes everything and
+    returns the images of the LAST launch on rank 0.  Every launch is fully rendered, gathered and assembled."""
+
+    def __init__(self, plan, rank, group=None):
+        self.plan, self.rank, self.group = plan, rank, group
+        self.slots = [plan.buffers(rank), plan.buffers(rank)]
+        self.cuda = plan.device.type == "cuda"
+        self.side = torch.cuda.Stream(device=plan.device) if (self.cuda and rank == 0 and plan.world > 1) else None
+        self.work = [None, None]             # per slot: handle of the gather in flight
+        self.done = [None, None]             # per slot (rank 0, cuda): event recorded after the slot's assembly
+        self.launch = [-1, -1]               # per slot: index of the launch occupying it
+        self.n = 0
+        self.last = None
+        self.on_assembled = None             # optional hook(launch_index, images) on rank 0 (tests)
+
+    def _complete(self, slot):
+        """finish the launch occupying `slot`: its gather, and on rank 0 the assembly (on the side stream when
+        there is one, so that the render stream is not held up)"""
+        work = self.work[slot]
+        if work is None:
+            return
+        self.work[slot] = None
+        local, gathered, image = self.slots[slot]
+        if self.side is not None:
+            with torch.cuda.stream(self.side):
+                work.wait()                                    # the side stream waits for the gather
+                self.last = self.plan.assemble(gathered, image)
+                if self.on_assembled:
+                    self.on_assembled(self.launch[slot], self.last)
+                ev = torch.cuda.Event()
+                ev.record(self.side)
+            self.done[slot] = ev
+        else:
+            work.wait()                                        # (cuda: the render stream waits; cpu: blocks)
+            if self.rank == 0:
+                self.last = self.plan.assemble(gathered, image)
+                if self.on_assembled:
+                    self.on_assembled(self.launch[slot], self.last)
+
+    def submit(self, render_fn):
+        slot = self.n & 1
+        self._complete(slot)                                   # normally already done at the previous submit
+        if self.done[slot] is not None:                        # rank 0: slot buffers are free once assembled
+            torch.cuda.current_stream(self.plan.device).wait_event(self.done[slot])
+            self.done[slot] = None
+        local, gathered, image = self.slots[slot]
+        self.launch[slot] = self.n
+        render_fn(self.rank, self.plan.world, self.plan.strip_rows, local)
+        if self.plan.world == 1:
+            self.last = local[:, : self.plan.height]
+            if self.on_assembled:
+                self.on_assembled(self.n, self.last)
+        else:
+            self.work[slot] = dist.gather(
+                local, gather_list=[gathered[r] for r in range(self.plan.world)] if self.rank == 0 else None,
+                dst=0, group=self.group, async_op=True)
+            if self.side is not None:
+                self._complete(slot ^ 1)                       # assemble the PREVIOUS launch while this one renders
+        self.n += 1
+
+    def drain(self):
+        first = self.n & 1                                     # older launch first
+        self._complete(first)
+        self._complete(first ^ 1)
+        if self.side is not None:
+            torch.cuda.current_stream(self.plan.device).wait_stream(self.side)
+        self.done = [None, None]
+        return self.last if self.rank == 0 else None

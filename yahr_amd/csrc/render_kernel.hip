@@ -207,9 +207,9 @@ YD int wave_min_i32(int v) {
 // when no lane can produce a NaN in it.
 // Returns n when the traversal is complete, or (ADAPT only) the node index at which the wave gave up being a
 // packet: lane l then continues at max(i, wake_l) with its tmax / hit (outputs), see traverse_packet.
-template <bool STATS, bool FAST, bool ADAPT>
-YD int packet_loop(const DScene &sc, bool active, bool any_hit, V3 o, V3 u, V3 inv, float &tmax, Hit &hit, int &wake,
-                   Counters &c) {
+template <bool STATS, bool FAST, bool ADAPT, bool ANY>
+YD int packet_loop(const DScene &sc, bool active, V3 o, V3 u, V3 inv, float &tmax, Hit &hit, int &wake, Counters &c) {
+  constexpr bool any_hit = ANY;                        // first-hit (shadow) mode is a compile-time property here
   const int n = sc.n_nodes;
   wake = active ? 0 : YD_DONE;
   int i = 0;                                           // wave-uniform: lives in an SGPR
@@ -225,18 +225,19 @@ YD int packet_loop(const DScene &sc, bool active, bool any_hit, V3 o, V3 u, V3 i
     }
     const int a = __float_as_int(cur.lo.w), b = __float_as_int(cur.hi.w);
     const NodeRec nseq = load_node(sc, i + 1);         // padded array: in bounds even for the last node
-    PrimRec pcur;
-    if (b >= 0) pcur = load_prim(sc, b);               // leaf: first primitive (padded array)
     const bool on = wake <= i;
     if (ADAPT) useful += (int)lanes(on);
     if (STATS) { c.box += on ? 1u : 0u; c.wave_nodes++; }
-    // branch-free for all lanes, masked afterwards; "any lane" is decided on the two compare masks themselves
-    const bool hs = FAST ? slab_hit_fast(xyz(cur.lo), xyz(cur.hi), o, inv, tmax)
-                         : slab_hit(xyz(cur.lo), xyz(cur.hi), o, inv, tmax);
-    const bool h = hs & on;
-    const bool anyh = (__builtin_amdgcn_ballot_w64(hs) & __builtin_amdgcn_ballot_w64(on)) != 0ULL;
     int next = i + 1;
-    if (b >= 0) {                                      // leaf (wave-uniform branch)
+    // ONE wave-uniform branch per node; the slab test is written out in both arms on purpose (testing the
+    // leaf flag twice made the compiler carry it as a 64-bit lane mask: ~8 extra scalar instructions per step)
+    if (b >= 0) {                                      // leaf
+      PrimRec pcur = load_prim(sc, b);                 // first primitive, requested before the slab test
+      // branch-free for all lanes, masked afterwards; "any lane" is decided on the two compare masks themselves
+      const bool hs = FAST ? slab_hit_fast(xyz(cur.lo), xyz(cur.hi), o, inv, tmax)
+                           : slab_hit(xyz(cur.lo), xyz(cur.hi), o, inv, tmax);
+      const bool h = hs & on;
+      const bool anyh = (__builtin_amdgcn_ballot_w64(hs) & __builtin_amdgcn_ballot_w64(on)) != 0ULL;
       if (anyh) {
         bool got = false;
         for (int k = 0; k < a; ++k) {
@@ -257,7 +258,11 @@ YD int packet_loop(const DScene &sc, bool active, bool any_hit, V3 o, V3 u, V3 i
           }
         }
       }
-    } else {
+    } else {                                           // interior
+      const bool hs = FAST ? slab_hit_fast(xyz(cur.lo), xyz(cur.hi), o, inv, tmax)
+                           : slab_hit(xyz(cur.lo), xyz(cur.hi), o, inv, tmax);
+      const bool h = hs & on;
+      const bool anyh = (__builtin_amdgcn_ballot_w64(hs) & __builtin_amdgcn_ballot_w64(on)) != 0ULL;
       wake = (on & !h) ? a : wake;
       next = anyh ? i + 1 : a;
     }
@@ -278,8 +283,15 @@ YD void traverse_packet(const DScene &sc, bool active, bool any_hit, V3 o, V3 u,
   // every node box finite (host check) and no active lane able to form 0*inf or inf-inf in the slab test?
   const bool fast = sc.boxes_finite != 0 && !wany(active & !slab_safe(o, inv));
   int wake, i;
-  if (fast) i = packet_loop<STATS, true, ADAPT>(sc, active, any_hit, o, u, inv, tmax, hit, wake, c);
-  else i = packet_loop<STATS, false, ADAPT>(sc, active, any_hit, o, u, inv, tmax, hit, wake, c);
+  // four copies of the loop (fast/exact slab x closest/first hit), selected once per traversal: run-time flags
+  // inside the loop cost scalar instructions on every step
+  if (fast) {
+    if (any_hit) i = packet_loop<STATS, true, ADAPT, true>(sc, active, o, u, inv, tmax, hit, wake, c);
+    else i = packet_loop<STATS, true, ADAPT, false>(sc, active, o, u, inv, tmax, hit, wake, c);
+  } else {
+    if (any_hit) i = packet_loop<STATS, false, ADAPT, true>(sc, active, o, u, inv, tmax, hit, wake, c);
+    else i = packet_loop<STATS, false, ADAPT, false>(sc, active, o, u, inv, tmax, hit, wake, c);
+  }
   if (ADAPT && i < n) {
     // a lane that already has its first hit in any-hit mode is parked at YD_DONE >= n
     lane_loop<STATS>(sc, wake > i ? wake : i, any_hit, o, u, inv, tmax, hit, c);

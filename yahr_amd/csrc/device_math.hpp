@@ -70,11 +70,11 @@ YD bool slab_hit_fast(V3 lo, V3 hi, V3 o, V3 inv, float tmax) {
   const float tfar = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax));
   return !(tnear > tfar);
 }
-YD bool finite_nonzero(float x) { const float a = fabsf(x); return a > 0.0f && a < __builtin_huge_valf(); }
+YD bool finite_nonzero(float x) { const float a = fabsf(x); return (a > 0.0f) & (a < __builtin_huge_valf()); }
 YD bool finite_f(float x) { return fabsf(x) < __builtin_huge_valf(); }
 YD bool slab_safe(V3 o, V3 inv) {
-  return finite_f(o.x) && finite_f(o.y) && finite_f(o.z) &&
-         finite_nonzero(inv.x) && finite_nonzero(inv.y) && finite_nonzero(inv.z);
+  return finite_f(o.x) & finite_f(o.y) & finite_f(o.z) &
+         finite_nonzero(inv.x) & finite_nonzero(inv.y) & finite_nonzero(inv.z);
 }
 
 // ---- Shapes.hs:36-59 collideTriangle, geometric part ---------------------------------------------
@@ -89,8 +89,8 @@ YD bool tri_candidate(V3 p0, V3 e1, V3 e2, V3 o, V3 u, float tmax, float &t, flo
   b1 = dot(s1, s) * inv;
   b2 = dot(s2, u) * inv;
   float b0 = (1.0f - b1) - b2;
-  return b0 >= 0.0f && b0 <= 1.0f && b1 >= 0.0f && b1 <= 1.0f && b2 >= 0.0f && b2 <= 1.0f &&
-         t > 0.0f && t <= tmax;
+  return (b0 >= 0.0f) & (b0 <= 1.0f) & (b1 >= 0.0f) & (b1 <= 1.0f) & (b2 >= 0.0f) & (b2 <= 1.0f) &
+         (t > 0.0f) & (t <= tmax);
 }
 // The same test cut in two for the packet walker (identical operations and values, only regrouped): stage 1
 // needs s, s1, the determinant and its reciprocal and yields b1 with its range test; when no lane of the
@@ -100,14 +100,16 @@ YD bool tri_stage1(V3 p0, V3 e1, V3 e2, V3 o, V3 u, V3 &s, float &inv, float &b1
   const V3 s1 = cross(u, e2);
   inv = 1.0f / dot(s1, e1);
   b1 = dot(s1, s) * inv;
-  return b1 >= 0.0f && b1 <= 1.0f;
+  // bitwise & on purpose (here and below): the comparisons are pure, and short-circuit && makes the compiler
+  // build exec-mask branches around every term
+  return (b1 >= 0.0f) & (b1 <= 1.0f);
 }
 YD bool tri_stage2(V3 e1, V3 e2, V3 s, V3 u, float inv, float b1, float tmax, float &t, float &b2) {
   const V3 s2 = cross(s, e1);
   t = dot(s2, e2) * inv;
   b2 = dot(s2, u) * inv;
   const float b0 = (1.0f - b1) - b2;
-  return b0 >= 0.0f && b0 <= 1.0f && b2 >= 0.0f && b2 <= 1.0f && t > 0.0f && t <= tmax;
+  return (b0 >= 0.0f) & (b0 <= 1.0f) & (b2 >= 0.0f) & (b2 <= 1.0f) & (t > 0.0f) & (t <= tmax);
 }
 YD V3 tri_shading_normal(float b1, float b2, V3 n0, V3 n1, V3 n2) {                  // Shapes.hs:47-48
   float b0 = (1.0f - b1) - b2;

@@ -109,6 +109,19 @@ def load_traffic(workload):
     return None
 
 
+def load_valu_profile(workload, frames_per_launch):
+    """(VALU wave-instructions per launch, measured VALU issue peak in G instr/s) from the committed PMC profile,
+    valid for the profiled configuration only (8 frames per launch, 1 GPU); else None."""
+    p = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    try:
+        j = json.load(open(p))
+        if j.get("workload") == workload and frames_per_launch == 8 and "valu_insts_per_launch" in j:
+            return j["valu_insts_per_launch"], j["valu_issue_peak_ginst_s"]
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -248,6 +261,13 @@ def main():
                                  "exceed what a DRAM stream could reach -- the kernel is VALU/latency bound"},
             "image_checksum": checksum,
         }
+        vp = load_valu_profile(args.workload, F) if world == 1 else None
+        if vp is not None:
+            # what actually bounds the kernel: vector-instruction issue
+            g = vp[0] / (kernel_ms_avg * 1e-3) / 1e9
+            out["roofline"]["valu_issue"] = {"achieved": round(g, 1), "peak": vp[1], "unit": "G wave-instr/s",
+                                             "frac": round(g / vp[1], 4),
+                                             "source": "SQ_INSTS_VALU of profiles/ / live launch time; peak measured by tools/ubench/valu_rate.hip"}
         if world == 1 and not args.no_cpu_baseline:
             cores = min(16, os.cpu_count() or 1)
             cb, ost = cpu_baseline(desc, cores, spp)

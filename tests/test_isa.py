@@ -20,9 +20,12 @@ CSRC = os.path.join(ROOT, "yahr_amd", "csrc")
 @pytest.fixture(scope="module")
 def asm(tmp_path_factory):
     out = tmp_path_factory.mktemp("isa") / "render_kernel.s"
+    # same code-generation flags as yahr_amd/csrc/Makefile (HIPFLAGS)
+    mk = open(os.path.join(CSRC, "Makefile")).read()
+    assert "-ffp-contract=off" in mk and "-fno-slp-vectorize" in mk
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
-                    "-S", "--cuda-device-only", os.path.join(CSRC, "render_kernel.hip"), "-o", str(out)],
-                   check=True, capture_output=True)
+                    "-fno-slp-vectorize", "-S", "--cuda-device-only", os.path.join(CSRC, "render_kernel.hip"),
+                    "-o", str(out)], check=True, capture_output=True)
     return open(out).read()
 
 

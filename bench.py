@@ -161,7 +161,9 @@ def main():
     trav = {"auto": yahr_amd.TRAVERSE_AUTO, "lane": yahr_amd.TRAVERSE_LANE, "packet": yahr_amd.TRAVERSE_PACKET,
             "hybrid": yahr_amd.TRAVERSE_HYBRID}[args.traverse]
     # frames per launch: the largest divisor of K not above the request, so that EXACTLY K frames are timed
-    F = max(1, min(args.frames_per_launch, args.steps))
+    # (the request scales with the rank count: every rank then gets as many tiles per launch as in the 1-GPU case,
+    # so the per-launch tail stays amortised and the gathers get larger and fewer)
+    F = max(1, min(args.frames_per_launch * world, args.steps))
     while args.steps % F:
         F -= 1
     n_launches = args.steps // F

@@ -379,3 +379,21 @@ def test_frame_batch_equals_single_frames(gpu):
     imgs = plan.assemble(parts).cpu().numpy()
     assert np.array_equal(bits(imgs[0]), bits(one)) and np.array_equal(bits(imgs[1]), bits(one))
     ctx.close()
+
+
+# ---- the largest BASELINE scene: 1M random triangles, deep BVH (config 5) at a size the oracle finishes quickly ----
+def test_one_million_triangles_deep_bvh(gpu):
+    d = scenes.random_tris(1_000_000, 240, 135, depth=2, bvh_depth=20)
+    scene = d.to_scene().build()
+    assert scene.flat.contents.n_prims == 1_000_000 and scene.flat.contents.n_nodes > 1_000_000
+    ref, ost = oracle_render(d)
+    imgs = {}
+    for m in MODES + [yahr_amd.TRAVERSE_AUTO]:
+        img, st = yahr_amd.render_image(scene, traverse=m, collect_stats=True)
+        assert outside_tol(img, ref) == 0, m
+        for k in ("primary_rays", "reflection_rays", "shadow_rays", "shaded_hits", "box_tests", "tri_tests"):
+            assert st[k] == ost[k], (k, m)
+        imgs[m] = img
+    for m in imgs:
+        assert np.array_equal(bits(imgs[m]), bits(imgs[MODES[0]]))
+    assert (ref.sum(axis=2) > 0).mean() > 0.2

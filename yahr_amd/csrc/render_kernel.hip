@@ -150,14 +150,15 @@ YD bool test_prim_packet(const DScene &sc, int idx, const PrimRec &p, bool live,
 
 // ---- lane walker --------------------------------------------------------------------------------
 // continues a traversal from per-lane node index i (>= n: nothing left) with the lane's current tmax / hit
-template <bool STATS>
+template <bool STATS, bool FAST>
 YD void lane_loop(const DScene &sc, int i, bool any_hit, V3 o, V3 u, V3 inv, float tmax, Hit &hit, Counters &c) {
   const int n = sc.n_nodes;
   while (i < n) {
     const NodeRec nd = load_node(sc, i);
     const int a = __float_as_int(nd.lo.w), b = __float_as_int(nd.hi.w);
     if (STATS) c.box++;
-    const bool h = slab_hit(xyz(nd.lo), xyz(nd.hi), o, inv, tmax);
+    const bool h = FAST ? slab_hit_fast(xyz(nd.lo), xyz(nd.hi), o, inv, tmax)
+                        : slab_hit(xyz(nd.lo), xyz(nd.hi), o, inv, tmax);
     int next = (b >= 0 || h) ? i + 1 : a;
     if (h && b >= 0) {
       for (int k = 0; k < a; ++k) {
@@ -175,7 +176,10 @@ template <bool STATS>
 YD void traverse_lane(const DScene &sc, bool active, bool any_hit, V3 o, V3 u, float tmax, Hit &hit, Counters &c) {
   const V3 inv = v3(1.0f / u.x, 1.0f / u.y, 1.0f / u.z);
   hit.prim = -1; hit.t = 0.0f; hit.b1 = 0.0f; hit.b2 = 0.0f;
-  lane_loop<STATS>(sc, active ? 0 : sc.n_nodes, any_hit, o, u, inv, tmax, hit, c);
+  // NaN-free slab form when the whole wave qualifies (see traverse_packet / device_math.hpp)
+  const bool fast = sc.boxes_finite != 0 && !wany(active & !slab_safe(o, inv));
+  if (fast) lane_loop<STATS, true>(sc, active ? 0 : sc.n_nodes, any_hit, o, u, inv, tmax, hit, c);
+  else lane_loop<STATS, false>(sc, active ? 0 : sc.n_nodes, any_hit, o, u, inv, tmax, hit, c);
 }
 
 // ---- packet walker ------------------------------------------------------------------------------
@@ -294,7 +298,8 @@ YD void traverse_packet(const DScene &sc, bool active, bool any_hit, V3 o, V3 u,
   }
   if (ADAPT && i < n) {
     // a lane that already has its first hit in any-hit mode is parked at YD_DONE >= n
-    lane_loop<STATS>(sc, wake > i ? wake : i, any_hit, o, u, inv, tmax, hit, c);
+    if (fast) lane_loop<STATS, true>(sc, wake > i ? wake : i, any_hit, o, u, inv, tmax, hit, c);
+    else lane_loop<STATS, false>(sc, wake > i ? wake : i, any_hit, o, u, inv, tmax, hit, c);
   }
 }
 

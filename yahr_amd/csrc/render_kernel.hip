@@ -197,10 +197,21 @@ YD void traverse_lane(const DScene &sc, bool active, bool any_hit, V3 o, V3 u, f
 #define YD_MIN_ACTIVE 14
 #endif
 
+// Wave-wide minimum through the DPP cross-lane path (row shifts, then the two row broadcasts of gfx9): six VALU
+// instructions and one v_readlane instead of six LDS round trips (ds_bpermute).  Needs the whole wave executing,
+// which holds at every call site (traversal control flow is wave-uniform and no lane ever leaves a kernel early).
 YD int wave_min_i32(int v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) { int w = __shfl_xor(v, off, 64); v = w < v ? w : v; }
-  return v;
+  constexpr int id = 0x7fffffff;
+#define YD_MIN_STEP(ctrl, rows)                                                             \
+  { const int w = __builtin_amdgcn_update_dpp(id, v, ctrl, rows, 0xf, false); v = w < v ? w : v; }
+  YD_MIN_STEP(0x111, 0xf)                              // row_shr:1
+  YD_MIN_STEP(0x112, 0xf)                              // row_shr:2
+  YD_MIN_STEP(0x114, 0xf)                              // row_shr:4
+  YD_MIN_STEP(0x118, 0xf)                              // row_shr:8   -> lane 15 of every row holds its row's min
+  YD_MIN_STEP(0x142, 0xa)                              // row_bcast:15 into rows 1 and 3
+  YD_MIN_STEP(0x143, 0xc)                              // row_bcast:31 into rows 2 and 3 -> lane 63 holds the min
+#undef YD_MIN_STEP
+  return __builtin_amdgcn_readlane(v, 63);
 }
 
 // The node index i is wave-uniform, so node and primitive records arrive through SCALAR loads into SGPRs.

@@ -180,7 +180,10 @@ typedef struct yahr_render_opts {
    * s % n_shards == shard, compacted top to bottom into the output.  n_shards <= 1: rows [row0,row1). */
   int32_t n_shards, shard, strip_rows;
   int32_t tuning;              /* 0 = defaults; bit 0: XCD band swizzle of the tile order (diagnostics: slower);
-                                  bit 1: dispatch centre tile rows first (diagnostics: measured slower) */
+                                  bit 1: dispatch centre tile rows first (diagnostics: measured slower);
+                                  bit 2 (YAHR_TUNE_REGROUP): workgroups of 4 waves (2x2 tiles) that pack their
+                                  active rays into the fewest waves before every traversal (diagnostics:
+                                  same image, measured slower -- the walkers are latency bound) */
   /* Frame batch: frames > 1 renders that many frames in ONE launch (tiles of all frames interleaved, so the
    * tail of one frame overlaps the others).  Frame f lands at d_rgb + f * frame_rows * width * 3 and uses camera f of
    * yahr_ctx_set_cameras (the scene camera when none were set).  0 and 1 mean a single frame. */
@@ -188,6 +191,10 @@ typedef struct yahr_render_opts {
   int32_t frame_rows;          /* rows between consecutive frames in d_rgb; 0 = packed (the rows rendered) */
   int32_t reserved[4];
 } yahr_render_opts;
+
+#define YAHR_TUNE_XCD_BANDS 1
+#define YAHR_TUNE_CENTRE_FIRST 2
+#define YAHR_TUNE_REGROUP 4
 
 typedef struct yahr_stats {
   uint64_t primary_rays, reflection_rays, shadow_rays;   /* rays actually cast */

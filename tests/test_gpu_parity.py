@@ -397,3 +397,84 @@ def test_one_million_triangles_deep_bvh(gpu):
     for m in imgs:
         assert np.array_equal(bits(imgs[m]), bits(imgs[MODES[0]]))
     assert (ref.sum(axis=2) > 0).mean() > 0.2
+
+
+def test_rccl_gather_pipeline_one_rank(gpu, tmp_path):
+    """The collective leg of yahr_amd.dist on the real backend: a ONE-rank RCCL group (all a one-GPU box allows;
+    two ranks on one GPU are refused by RCCL) with the gather + side-stream assembly forced on.  Every launch's
+    assembled frames must equal a direct render bit for bit, with launches overlapping (double buffering)."""
+    import torch
+    import torch.distributed as dist
+    from yahr_amd.dist import ShardPipeline, ShardPlan, render_sharded
+    d = scenes.pseudo_bunny(160, 90, n_lon=40, n_lat=20)
+    scene = d.to_scene().build()
+    full, _ = yahr_amd.render_image(scene)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method="file://" + str(tmp_path / "rdzv"), rank=0, world_size=1, device_id=dev)
+    try:
+        ctx = yahr_amd.Context(scene, 0)
+        frames = 3
+        plan = ShardPlan(scene.height, scene.width, 1, 8, device=dev, frames=frames)
+        pipe = ShardPipeline(plan, 0, force_collective=True)
+        assert pipe.side is not None
+        seen = {}
+        pipe.on_assembled = lambda i, imgs: seen.__setitem__(i, imgs.clone())
+        stream = torch.cuda.current_stream()
+        o = yahr_amd.make_opts(n_shards=1, shard=0, strip_rows=8, frames=frames, frame_rows=plan.max_rows)
+
+        def render_fn(shard, n_shards, strip_rows, out):
+            ctx.render_into(out.data_ptr(), 0, scene.height, o, stream.cuda_stream)
+
+        for _ in range(5):
+            pipe.submit(render_fn)
+        last = pipe.drain()
+        torch.cuda.synchronize()
+        assert sorted(seen) == [0, 1, 2, 3, 4]
+        for i, imgs in seen.items():
+            for f in range(frames):
+                assert np.array_equal(bits(imgs[f].cpu().numpy()), bits(full)), (i, f)
+        assert np.array_equal(bits(last[frames - 1].cpu().numpy()), bits(full))
+        one = render_sharded(render_fn, plan, 0, force_collective=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(bits(one[0].cpu().numpy()), bits(full))
+        t = torch.ones(4, device=dev)
+        dist.all_reduce(t)
+        dist.barrier()
+        assert float(t.sum()) == 4.0
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_regrouped_rays_give_the_same_image(gpu):
+    """tuning bit 2 (workgroups of 4 waves that pack their active rays before every traversal) must not change a
+    single bit or count: whole tiles, ragged edges, row shards, frame batches, reference windows, spp > 1."""
+    import torch
+    for d in (scenes.pseudo_bunny(203, 117, n_lon=48, n_lat=25), scenes.random_tris(3000, 97, 61, bvh_depth=12),
+              scenes.scene_fixed(64, 48)):
+        scene = d.to_scene().build()
+        for m in MODES:
+            ref, st0 = yahr_amd.render_image(scene, traverse=m, collect_stats=True)
+            img, st1 = yahr_amd.render_image(scene, traverse=m, collect_stats=True, tuning=yahr_amd.TUNE_REGROUP)
+            assert np.array_equal(bits(img), bits(ref)), m
+            for k in ("primary_rays", "reflection_rays", "shadow_rays", "shaded_hits", "box_tests", "tri_tests", "sphere_tests"):
+                assert st0[k] == st1[k], (k, m)
+        ref, _ = yahr_amd.render_image(scene)
+        img, _ = yahr_amd.render_image(scene, tiles=yahr_amd.TILES_REFERENCE, tuning=yahr_amd.TUNE_REGROUP)
+        assert np.array_equal(bits(img), bits(ref))
+        ref4, _ = yahr_amd.render_image(scene, spp=4, seed=3)
+        img4, _ = yahr_amd.render_image(scene, spp=4, seed=3, tuning=yahr_amd.TUNE_REGROUP)
+        assert np.array_equal(bits(img4), bits(ref4))
+        ctx = yahr_amd.Context(scene, 0)
+        part = ctx.render(n_shards=3, shard=1, strip_rows=8, tuning=yahr_amd.TUNE_REGROUP)
+        rows = yahr_amd.shard_global_rows(scene.height, 3, 1, 8)
+        torch.cuda.synchronize()
+        assert np.array_equal(bits(part.cpu().numpy()[: len(rows)]), bits(ref[rows]))
+        out = torch.zeros((3, scene.height, scene.width, 3), device="cuda:0")
+        ctx.render_into(out.data_ptr(), 0, scene.height, yahr_amd.make_opts(frames=3, tuning=yahr_amd.TUNE_REGROUP),
+                        torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        for f in range(3):
+            assert np.array_equal(bits(out[f].cpu().numpy()), bits(ref)), f
+        ctx.close()

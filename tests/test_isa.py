@@ -5,7 +5,7 @@ by accident (a store ahead of a scene load, an `asm volatile`, a shuffle result 
 the kernel stays CORRECT but silently falls back to per-lane gathers and runs 2x slower.  These tests pin:
   * node / primitive records of the packet walker arrive through scalar loads (s_load_dwordx8 / x4),
   * no FMA contraction anywhere outside the IEEE divide / sqrt expansions (parity with the non-fused reference),
-  * no scratch (register spilling to memory), register budget fits at least 4 waves per SIMD.
+  * packet walker: no scratch (register spilling to memory), at least 4 waves per SIMD; lane walker: 8 waves.
 """
 import os
 import re
@@ -29,20 +29,26 @@ def asm(tmp_path_factory):
     return open(out).read()
 
 
-def kernel_body(asm, mangled):
-    m = re.search(r"^%s:[^\n]*\n(.*?)s_endpgm" % re.escape(mangled), asm, flags=re.S | re.M)
-    assert m, mangled
+def kernel_body(asm, prefix):
+    """body of the kernel whose mangled name starts with `prefix` (template arguments; the parameter list follows)"""
+    m = re.search(r"^%s\w*:[^\n]*\n(.*?)s_endpgm" % re.escape(prefix), asm, flags=re.S | re.M)
+    assert m, prefix
     return m.group(1)
 
 
-def meta(asm, mangled):
-    m = re.search(r"\.name:\s+%s\n(.*?)\.wavefront_size" % re.escape(mangled), asm, flags=re.S)
-    assert m, mangled
+def meta(asm, prefix):
+    m = re.search(r"\.name:\s+%s\w*\n(.*?)\.wavefront_size" % re.escape(prefix), asm, flags=re.S)
+    assert m, prefix
     return {k: int(v) for k, v in re.findall(r"\.(\w+):\s+(\d+)", m.group(1))}
 
 
-PACKET_FAST = "_Z8k_renderILi2ELb0EEv6DScene7RParamsPfPy"
-LANE_FAST = "_Z8k_renderILi1ELb0EEv6DScene7RParamsPfPy"
+# k_render<MODE, STATS, WPB>: MODE 1 lane / 2 packet / 3 adaptive; WPB waves per workgroup (4 = ray regrouping)
+PACKET_FAST = "_Z8k_renderILi2ELb0ELi1EE"
+LANE_FAST = "_Z8k_renderILi1ELb0ELi1EE"
+ADAPTIVE_FAST = "_Z8k_renderILi3ELb0ELi1EE"
+PACKET_STATS = "_Z8k_renderILi2ELb1ELi1EE"
+PACKET_REGROUP = "_Z8k_renderILi2ELb0ELi4EE"
+ADAPTIVE_REGROUP = "_Z8k_renderILi3ELb0ELi4EE"
 
 
 def test_packet_walker_uses_scalar_loads(asm):
@@ -56,6 +62,12 @@ def test_packet_walker_uses_scalar_loads(asm):
     assert vmem <= 16, vmem
     lane = kernel_body(asm, LANE_FAST)
     assert len(re.findall(r"global_load_dword", lane)) >= 10      # the lane walker gathers per lane, by design
+    # the record arrays are `const __restrict__` kernel arguments, so counters (atomics, clock reads) and the
+    # workgroup barriers of the regrouping variants do not cost the packet walker its scalar loads either
+    for k in (PACKET_STATS, PACKET_REGROUP, ADAPTIVE_REGROUP):
+        body = kernel_body(asm, k)
+        assert len(re.findall(r"s_load_dwordx8", body)) >= 5, k
+    assert "s_barrier" in kernel_body(asm, PACKET_REGROUP)
 
 
 def test_no_fma_contraction(asm):
@@ -69,8 +81,15 @@ def test_no_fma_contraction(asm):
 
 
 def test_register_budget_and_no_scratch(asm):
-    for k in (PACKET_FAST, LANE_FAST):
+    # packet walker (compute bound): no spilling to scratch memory at all, >= 4 waves per SIMD
+    for k in (PACKET_FAST, PACKET_REGROUP):
         m = meta(asm, k)
-        assert m["private_segment_fixed_size"] == 0, m          # no spilling to scratch memory
+        assert m["private_segment_fixed_size"] == 0, m
         assert m["vgpr_spill_count"] == 0
-        assert m["vgpr_count"] <= 128, m                         # >= 4 waves per SIMD
+        assert m["vgpr_count"] <= 128, m
+    # lane / adaptive walkers (gather-latency bound): built for all 8 wave slots of a SIMD, i.e. 64 VGPRs; the
+    # values that do not fit (radiance state that is dead during a traversal) are spilled around the loops
+    for k in (LANE_FAST, ADAPTIVE_FAST):
+        m = meta(asm, k)
+        assert m["vgpr_count"] <= 64, m
+        assert m["vgpr_spill_count"] <= 48, m

@@ -15,6 +15,11 @@ from yahr_amd import scenes
 TR = {"lane": yahr_amd.TRAVERSE_LANE, "packet": yahr_amd.TRAVERSE_PACKET, "hybrid": yahr_amd.TRAVERSE_HYBRID,
       "auto": yahr_amd.TRAVERSE_AUTO}
 
+def _no_lights(d):
+    d.lights = []
+    return d
+
+
 ap = argparse.ArgumentParser()
 ap.add_argument("--scene", default="bunny")
 ap.add_argument("--rounds", type=int, default=15)
@@ -24,7 +29,9 @@ a = ap.parse_args()
 
 desc = {"bunny": lambda: scenes.pseudo_bunny(), "spheres": lambda: scenes.spheres8(),
         "bunny4": lambda: scenes.pseudo_bunny(depth=4),
-        "tris": lambda: scenes.random_tris(), "tris200k": lambda: scenes.random_tris(200000, bvh_depth=16)}[a.scene]()
+        "tris": lambda: scenes.random_tris(), "tris200k": lambda: scenes.random_tris(200000, bvh_depth=16),
+        "tris_d1": lambda: scenes.random_tris(depth=1),            # primary + shadow rays
+        "tris_primary": lambda: _no_lights(scenes.random_tris(depth=1))}[a.scene]()
 scene = desc.to_scene().build()
 ctx = yahr_amd.Context(scene, 0)
 MAXF = 32

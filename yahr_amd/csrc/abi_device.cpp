@@ -263,13 +263,18 @@ int yahr_ctx_render(yahr_ctx *c, int32_t row0, int32_t row1, const yahr_render_o
   // XCDs round-robin, statically, and image regions differ in cost by orders of magnitude), so the natural
   // tile order -- neighbouring tiles on different XCDs, perfectly balanced -- is the default.
   rp.xcd_swizzle = (o.tuning & 1) ? 1 : 0;
+  // regroup rays between traversals (workgroups of 4 waves).  Diagnostics: bit-identical output, but measured
+  // SLOWER everywhere (1M triangles adaptive 9.4 -> 11.6 ms, pseudo-bunny packet 0.51 -> 0.56): the walkers are
+  // bound by gather latency, not by idle lanes, and the workgroup barriers make 4 waves wait for the slowest
+  const bool regroup = (o.tuning & YAHR_TUNE_REGROUP) != 0;
   int n_blocks = 0;
   if (o.tiles == YAHR_TILES_REFERENCE) {
     if (o.n_shards > 1 || row0 != 0 || row1 != c->height) { set_error("reference tiles render the whole image only"); return YAHR_E_ARG; }
     int nb = o.n_batches > 0 ? o.n_batches : yahr_n_batches(1, c->width, c->height);
     int rc = ensure_windows(c, nb); if (rc) return rc;
     rp.tile_mode = 1; rp.windows = c->d_windows; rp.n_local_rows = c->height; rp.strip_rows = c->height > 0 ? c->height : 1; rp.n_shards = 1;
-    n_blocks = c->n_chunks;
+    rp.n_tiles = c->n_chunks;
+    n_blocks = regroup ? (c->n_chunks + 3) / 4 : c->n_chunks;
   } else {
     if (o.n_shards > 1) {
       if (o.shard < 0 || o.shard >= o.n_shards || o.strip_rows <= 0) { set_error("bad shard spec"); return YAHR_E_ARG; }
@@ -285,6 +290,7 @@ int yahr_ctx_render(yahr_ctx *c, int32_t row0, int32_t row1, const yahr_render_o
     const int tile_rows = (rp.n_local_rows + 7) / 8;
     rp.n_tiles = rp.tiles_x * tile_rows;
     n_blocks = ((rp.n_tiles + 7) / 8) * 8;     // the XCD swizzle needs a multiple of 8 blocks
+    if (regroup) n_blocks = ((rp.tiles_x + 1) / 2) * ((tile_rows + 1) / 2);     // a workgroup owns 2x2 tiles
     // centre-rows-first dispatch measured 9 % SLOWER than natural order on the pseudo-bunny (the long chains
     // all start together and nothing cheap is left to pack around them): diagnostics only, tuning bit 1
     if ((o.tuning & 3) == 2 && tile_rows > 2) {
@@ -304,7 +310,7 @@ int yahr_ctx_render(yahr_ctx *c, int32_t row0, int32_t row1, const yahr_render_o
     n_blocks *= rp.frames;
   }
   HIP_TRY(hipEventRecord(c->ev0, st));
-  HIP_TRY(yahr_dev::launch_render(c->ds, rp, pick_mode(o.traverse, c->auto_mode), n_blocks, d_rgb, c->d_ctr, o.collect_stats != 0, st));
+  HIP_TRY(yahr_dev::launch_render(c->ds, rp, pick_mode(o.traverse, c->auto_mode), regroup, n_blocks, d_rgb, c->d_ctr, o.collect_stats != 0, st));
   HIP_TRY(hipEventRecord(c->ev1, st));
   c->timed = true;
   return YAHR_OK;

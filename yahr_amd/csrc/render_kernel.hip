@@ -40,10 +40,17 @@
 using namespace yd;
 
 // Tuning knobs (compile time).  YAHR_WAVES: waves per SIMD the register allocator must make room for.
+// The lane walker (and the adaptive walker that ends in it) waits on dependent per-lane gathers, a third of which
+// miss the L2: it is latency bound and wants every wave slot (1M triangles, adaptive: 9.3 ms at 5 waves/SIMD,
+// 8.2 at 6, 7.2 at 8 -- the 64-VGPR budget spills ~30 values, all outside the traversal loops).
+#ifndef YAHR_WAVES_LANE
+#define YAHR_WAVES_LANE 8
+#endif
 #ifndef YAHR_WAVES
 #define YAHR_WAVES 5   // swept 3..8 on the pseudo-bunny: flat within 4 % (the kernel is critical-path bound), 5 best
 #endif
-#define YAHR_KERNEL_ATTR __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(YAHR_WAVES, 8)))
+// waves per workgroup when rays are regrouped between traversals (yahr_render_opts.tuning bit 2)
+#define YAHR_REGROUP_WAVES 4
 
 namespace {
 
@@ -149,26 +156,43 @@ YD bool test_prim_packet(const DScene &sc, int idx, const PrimRec &p, bool live,
 }
 
 // ---- lane walker --------------------------------------------------------------------------------
+#ifndef YD_LEAF_SEARCHERS
+#define YD_LEAF_SEARCHERS 16
+#endif
 // continues a traversal from per-lane node index i (>= n: nothing left) with the lane's current tmax / hit
 template <bool STATS, bool FAST>
 YD void lane_loop(const DScene &sc, int i, bool any_hit, V3 o, V3 u, V3 inv, float tmax, Hit &hit, Counters &c) {
   const int n = sc.n_nodes;
-  while (i < n) {
-    const NodeRec nd = load_node(sc, i);
-    const int a = __float_as_int(nd.lo.w), b = __float_as_int(nd.hi.w);
-    if (STATS) c.box++;
-    const bool h = FAST ? slab_hit_fast(xyz(nd.lo), xyz(nd.hi), o, inv, tmax)
-                        : slab_hit(xyz(nd.lo), xyz(nd.hi), o, inv, tmax);
-    int next = (b >= 0 || h) ? i + 1 : a;
-    if (h && b >= 0) {
-      for (int k = 0; k < a; ++k) {
-        const PrimRec p = load_prim(sc, b + k);
-        if (test_prim_lane<STATS>(sc, b + k, p, o, u, tmax, hit, c)) {
-          if (any_hit) { next = n; break; }
+  // "while-while": a lane whose box test hits a leaf parks the leaf (pb, pa) and idles while the other lanes
+  // keep searching; the wave scans the parked leaves together once fewer than YD_LEAF_SEARCHERS lanes are
+  // still searching.  Per lane the order of tests is untouched (a parked lane does nothing until its leaf has
+  // been scanned, so every later box test sees the shrunken tmax).  Scanning a leaf the moment one lane finds
+  // it put a second, dependent gather (the primitive record) into ~85 % of the wave's iterations.
+  int pb = -1, pa = 0;
+  for (;;) {
+    const bool searching = i < n && pb < 0;
+    const unsigned ns = lanes(searching);
+    const bool parked = wany(pb >= 0);
+    if (ns == 0 && !parked) break;
+    if (ns >= YD_LEAF_SEARCHERS || !parked) {                   // node step (wave-uniform choice)
+      if (searching) {
+        const NodeRec nd = load_node(sc, i);
+        const int a = __float_as_int(nd.lo.w), b = __float_as_int(nd.hi.w);
+        if (STATS) c.box++;
+        const bool h = FAST ? slab_hit_fast(xyz(nd.lo), xyz(nd.hi), o, inv, tmax)
+                            : slab_hit(xyz(nd.lo), xyz(nd.hi), o, inv, tmax);
+        if (h && b >= 0) { pb = b; pa = a; }
+        i = (b >= 0 || h) ? i + 1 : a;
+      }
+    } else if (pb >= 0) {                                       // leaf step
+      for (int k = 0; k < pa; ++k) {
+        const PrimRec p = load_prim(sc, pb + k);
+        if (test_prim_lane<STATS>(sc, pb + k, p, o, u, tmax, hit, c)) {
+          if (any_hit) { i = n; break; }
         }
       }
+      pb = -1;
     }
-    i = next;
   }
 }
 
@@ -321,6 +345,81 @@ YD void traverse(const DScene &sc, bool active, bool any_hit, V3 o, V3 u, float 
   else traverse_packet<STATS, true>(sc, active, any_hit, o, u, tmax, hit, c);     // TRAV_ADAPTIVE
 }
 
+// The three record arrays reach every kernel as `const T *__restrict__` KERNEL ARGUMENTS (and are bound into the
+// kernel's private DScene copy): for such pointers the AMDGPU back end knows the memory is never written during
+// the kernel, so a wave-uniform load from them stays a scalar load (s_load_dwordx8 into SGPRs) whatever stores,
+// atomics or barriers come before it.  Reached through the pointer fields of the by-value DScene block instead,
+// the same loads silently became per-lane gathers as soon as anything that may write memory preceded them.
+#define YD_SCENE_PARAMS const float4 *__restrict__ a_nodes, const float4 *__restrict__ a_prims, \
+                        const float4 *__restrict__ a_normals
+#define YD_SCENE_BIND DScene sc = sc_in; sc.nodes = a_nodes; sc.prims = a_prims; sc.normals = a_normals;
+
+// ---- ray regrouping inside a workgroup of WPB waves ----------------------------------------------
+// Barrier whose fences cover LDS only: a full __syncthreads() fences global memory too, which makes every later
+// scene load "clobberable" and costs the packet walker its scalar loads (tests/test_isa.py).
+YD void block_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+template <int WPB>
+YD bool block_any(bool p, float *xch) {
+  if (WPB == 1) return wany(p);
+  int *flag = (int *)(xch + 12 * 64 * WPB) + WPB;      // behind ray[7], hit[4], src[1] and the wave counts
+  const bool w = wany(p);                              // (a traversal's barriers separate two calls)
+  if ((threadIdx.x & 63) == 0) flag[threadIdx.x >> 6] = w ? 1 : 0;
+  block_sync();
+  bool r = false;
+#pragma unroll
+  for (int k = 0; k < WPB; ++k) r |= flag[k] != 0;
+  return r;
+}
+
+// Secondary rays leave holes: only pixels whose primary ray hit something cast shadow and reflection rays (38 %
+// on the 1M-triangle scene), scattered over the tile.  With WPB > 1 the workgroup's active rays are packed, in
+// thread order, into the fewest waves before every traversal and the hits are handed back afterwards through
+// LDS; a wave left without rays skips the traversal.  Per ray nothing changes (same tests, same order).
+template <int MODE, bool STATS, int WPB>
+YD void traverse_block(const DScene &sc, bool active, bool any_hit, V3 o, V3 u, float tmax, Hit &hit, Counters &c,
+                       float *xch) {
+  if (WPB == 1) { traverse<MODE, STATS>(sc, active, any_hit, o, u, tmax, hit, c); return; }
+  constexpr int B = 64 * WPB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float *ray = xch, *hits = xch + 7 * B;
+  int *src = (int *)(xch + 11 * B), *cnt = src + B;
+  const unsigned long long m = __ballot(active);
+  if (lane == 0) cnt[wave] = (int)__popcll(m);
+  if (active) {
+    ray[tid] = o.x; ray[B + tid] = o.y; ray[2 * B + tid] = o.z;
+    ray[3 * B + tid] = u.x; ray[4 * B + tid] = u.y; ray[5 * B + tid] = u.z; ray[6 * B + tid] = tmax;
+  }
+  block_sync();
+  int base = 0, total = 0;
+#pragma unroll
+  for (int k = 0; k < WPB; ++k) { const int ck = cnt[k]; base += k < wave ? ck : 0; total += ck; }
+  if (active) src[base + (int)__popcll(m & ((1ULL << lane) - 1ULL))] = tid;
+  block_sync();
+  const bool mine = tid < total;
+  int s = 0;
+  V3 o2 = vof(0.0f), u2 = v3(0.0f, 0.0f, 1.0f); float t2 = 0.0f;
+  if (mine) {
+    s = src[tid];
+    o2 = v3(ray[s], ray[B + s], ray[2 * B + s]);
+    u2 = v3(ray[3 * B + s], ray[4 * B + s], ray[5 * B + s]); t2 = ray[6 * B + s];
+  }
+  Hit h2;
+  traverse<MODE, STATS>(sc, mine, any_hit, o2, u2, t2, h2, c);
+  if (mine) {
+    hits[s] = __int_as_float(h2.prim); hits[B + s] = h2.t; hits[2 * B + s] = h2.b1; hits[3 * B + s] = h2.b2;
+  }
+  block_sync();
+  hit.prim = -1; hit.t = 0.0f; hit.b1 = 0.0f; hit.b2 = 0.0f;
+  if (active) {
+    hit.prim = __float_as_int(hits[tid]); hit.t = hits[B + tid]; hit.b1 = hits[2 * B + tid]; hit.b2 = hits[3 * B + tid];
+  }
+}
+
 // ---- shading --------------------------------------------------------------------------------------
 // DifferentialGeometry of the accepted hit (Shapes.hs:23-28, 49-55); returns the material index
 YD int surface_of(const DScene &sc, V3 ro, V3 rd, const Hit &hit, V3 &x, V3 &n, V3 &dpdu) {
@@ -363,8 +462,10 @@ YD V3 material_at(const DScene &sc, int mat, V3 n, V3 dpdu, V3 wi, V3 wo) {
 //   phase 1..L   shadow probe towards light phase-1 (Lights.hs:15-24, Rays.hs:49-54); its contribution
 //                cv = |lightDir.n| @* k * intensity is formed BEFORE the probe so that only cv stays live
 //   after phase L: w_k, D_k to LDS, reflection ray (Integrators.hs:40-47)
-template <int MODE, bool STATS>
-YD V3 radiance(const DScene &sc, bool valid, V3 ro, V3 rd, float *lds, int lane, Counters &c, bool &bad_mat) {
+template <int MODE, bool STATS, int WPB>
+YD V3 radiance(const DScene &sc, bool valid, V3 ro, V3 rd, float *lds, float *xch, Counters &c, bool &bad_mat) {
+  constexpr int B = 64 * WPB;                                         // threads per workgroup
+  const int tid = threadIdx.x;
   bool alive = valid;
   int levels = 0;
   const int L = sc.n_lights, per = L + 1, n_steps = sc.depth * per;
@@ -374,7 +475,7 @@ YD V3 radiance(const DScene &sc, bool valid, V3 ro, V3 rd, float *lds, int lane,
     const int k = step / per, phase = step - k * per;
     V3 qo = ro, qd = rd; float qt = 1e6f; bool active;
     if (phase == 0) {
-      if (!wany(alive)) break;
+      if (!block_any<WPB>(alive, xch)) break;
       if (STATS) { if (k == 0) c.primary += lanes(alive); else c.reflection += lanes(alive); }
       active = alive;
       direct = vof(0.0f);
@@ -398,7 +499,7 @@ YD V3 radiance(const DScene &sc, bool valid, V3 ro, V3 rd, float *lds, int lane,
       if (STATS) c.shadow += lanes(active);
     }
     Hit hit;
-    traverse<MODE, STATS>(sc, active, phase != 0, qo, qd, qt, hit, c);
+    traverse_block<MODE, STATS, WPB>(sc, active, phase != 0, qo, qd, qt, hit, c, xch);
     if (phase == 0) {
       alive = alive && hit.prim >= 0;
       if (STATS) c.shaded += lanes(alive);
@@ -415,17 +516,17 @@ YD V3 radiance(const DScene &sc, bool valid, V3 ro, V3 rd, float *lds, int lane,
       const V3 r = rd - scale(2.0f * dot(rd, n), n);                  // reflectionDir, Integrators.hs:46-47
       const V3 f_r = material_at(sc, mat, n, dpdu, r, vneg(rd));
       const V3 w = scale(dot(n, r), f_r);
-      float *slot = lds + (size_t)k * 6 * 64 + lane;
-      slot[0] = w.x; slot[64] = w.y; slot[128] = w.z;
-      slot[192] = direct.x; slot[256] = direct.y; slot[320] = direct.z;
+      float *slot = lds + (size_t)k * 6 * B + tid;
+      slot[0] = w.x; slot[B] = w.y; slot[2 * B] = w.z;
+      slot[3 * B] = direct.x; slot[4 * B] = direct.y; slot[5 * B] = direct.z;
       levels = k + 1;
       ro = x + scale(0.001f, r); rd = r;                              // Integrators.hs:41-43
     }
   }
   V3 v = vof(0.0f);                                                   // vcast 0 _ = 0 / miss = 0
   for (int k = levels - 1; k >= 0; --k) {
-    const float *slot = lds + (size_t)k * 6 * 64 + lane;
-    V3 w = v3(slot[0], slot[64], slot[128]), d = v3(slot[192], slot[256], slot[320]);
+    const float *slot = lds + (size_t)k * 6 * B + tid;
+    V3 w = v3(slot[0], slot[B], slot[2 * B]), d = v3(slot[3 * B], slot[4 * B], slot[5 * B]);
     v = (w * v) + d;
   }
   return v;
@@ -456,22 +557,36 @@ YD void flush_counters(const Counters &c, unsigned long long *ctr, int lane) {
 
 }  // namespace
 
-// One wavefront (= one 64-thread workgroup) per tile: an 8x8-pixel tile, or one of the reference's
-// squareBatches windows (Sampling.hs:5-21) walked 64 pixels at a time, u-major like the reference.
-template <int MODE, bool STATS>
-__global__ YAHR_KERNEL_ATTR void k_render(DScene sc, RParams rp, float *__restrict__ out,
-                                          unsigned long long *__restrict__ ctr) {
+// One wavefront per tile: an 8x8-pixel tile, or one of the reference's squareBatches windows (Sampling.hs:5-21)
+// walked 64 pixels at a time, u-major like the reference.  WPB = 1: one wave per workgroup.  WPB = 4: a
+// workgroup owns 2x2 tiles (or 4 consecutive window chunks) and regroups its rays before every traversal
+// (traverse_block).
+template <int MODE, bool STATS, int WPB>
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(MODE == TRAV_PACKET ? YAHR_WAVES : YAHR_WAVES_LANE, 8)))
+void k_render(DScene sc_in, YD_SCENE_PARAMS, RParams rp, float *__restrict__ out, unsigned long long *__restrict__ ctr) {
   extern __shared__ float lds[];
-  const int lane = threadIdx.x;
+  YD_SCENE_BIND
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float *xch = lds + (size_t)(sc.depth > 0 ? sc.depth : 1) * 6 * 64 * WPB;   // exchange area (WPB > 1 only)
   Counters c = {};
   bool bad_mat = false;
   const unsigned long long t_start = STATS ? clock64() : 0ULL;
   // frame batch: the same tile of every frame of the batch sits next to each other in dispatch order
   const int frame = rp.frames > 1 ? (int)(blockIdx.x % (unsigned)rp.frames) : 0;
-  int tile = rp.frames > 1 ? (int)(blockIdx.x / (unsigned)rp.frames) : (int)blockIdx.x;
-  if (rp.tile_mode == 0 && rp.xcd_swizzle) {           // diagnostics: contiguous band of tiles per XCD
-    const int per = (rp.n_tiles + 7) >> 3;
-    tile = (tile & 7) * per + (tile >> 3);
+  const int unit = rp.frames > 1 ? (int)(blockIdx.x / (unsigned)rp.frames) : (int)blockIdx.x;
+  int tile = unit;
+  if (WPB == 1) {
+    if (rp.tile_mode == 0 && rp.xcd_swizzle) {         // diagnostics: contiguous band of tiles per XCD
+      const int per = (rp.n_tiles + 7) >> 3;
+      tile = (tile & 7) * per + (tile >> 3);
+    }
+  } else if (rp.tile_mode == 0) {                      // 2x2 tiles per workgroup
+    const int ux_n = (rp.tiles_x + 1) >> 1;
+    const int uy = unit / ux_n, ux = unit - uy * ux_n;
+    const int tx = ux * 2 + (wave & 1), ty = uy * 2 + (wave >> 1);
+    tile = tx < rp.tiles_x ? ty * rp.tiles_x + tx : rp.n_tiles;
+  } else {
+    tile = unit * WPB + wave;
   }
   const DCold *cam = rp.cams ? rp.cams + frame : sc.cold;
   out += (size_t)frame * rp.frame_stride;
@@ -493,10 +608,11 @@ __global__ YAHR_KERNEL_ATTR void k_render(DScene sc, RParams rp, float *__restri
     row = (size_t)lv;
   } else {
     // 64-pixel chunk of a reference window: {x0,y0,x1,y1}, {first pixel of the chunk, ...}; u-major order
-    const int4 win = rp.windows[2 * (size_t)tile], q = rp.windows[2 * (size_t)tile + 1];
+    const int tl = tile < rp.n_tiles ? tile : rp.n_tiles - 1;          // n_tiles = number of chunks here
+    const int4 win = rp.windows[2 * (size_t)tl], q = rp.windows[2 * (size_t)tl + 1];
     const int hh = win.w - win.y, npx = (win.z - win.x) * hh;
     const int p = q.x + lane;
-    valid = p < npx;
+    valid = tile < rp.n_tiles && p < npx;
     u = valid ? win.x + p / hh : 0;
     gv = valid ? win.y + p % hh : 0;
     row = (size_t)gv;
@@ -507,7 +623,7 @@ __global__ YAHR_KERNEL_ATTR void k_render(DScene sc, RParams rp, float *__restri
     if (rp.spp > 1) sample_offset(u, gv, s, rp.n_strata, rp.seed, du, dv);
     V3 ro, rd;
     camera_ray(cam, (float)u + du, (float)gv + dv, ro, rd);
-    const V3 v = radiance<MODE, STATS>(sc, valid, ro, rd, lds, lane, c, bad_mat);
+    const V3 v = radiance<MODE, STATS, WPB>(sc, valid, ro, rd, lds, xch, c, bad_mat);
     acc = (rp.spp > 1) ? acc + v : v;
   }
   if (rp.spp > 1) acc = scale(1.0f / (float)rp.spp, acc);
@@ -529,8 +645,9 @@ __global__ YAHR_KERNEL_ATTR void k_render(DScene sc, RParams rp, float *__restri
 
 // ---- diagnostic kernels: device functions on arbitrary rays (KAT checks on the GPU) -----------------
 template <int MODE>
-__global__ __launch_bounds__(64) void k_trace(DScene sc, int n, const float *__restrict__ rays, int any_hit,
-                                              int *__restrict__ prim_out, float *__restrict__ t_out) {
+__global__ __launch_bounds__(64) void k_trace(DScene sc_in, YD_SCENE_PARAMS, int n, const float *__restrict__ rays,
+                                              int any_hit, int *__restrict__ prim_out, float *__restrict__ t_out) {
+  YD_SCENE_BIND
   const int i = blockIdx.x * 64 + threadIdx.x;
   const bool valid = i < n;
   V3 o = vof(0.0f), d = v3(0, 0, 1); float tmax = 0.0f;
@@ -545,16 +662,17 @@ __global__ __launch_bounds__(64) void k_trace(DScene sc, int n, const float *__r
 
 // radiance of arbitrary rays; tMax of the given ray is ignored (the integrator casts with 1e6, like vcast)
 template <int MODE>
-__global__ __launch_bounds__(64) void k_radiance(DScene sc, int n, const float *__restrict__ rays,
+__global__ __launch_bounds__(64) void k_radiance(DScene sc_in, YD_SCENE_PARAMS, int n, const float *__restrict__ rays,
                                                  float *__restrict__ rgb, unsigned long long *__restrict__ ctr) {
   extern __shared__ float lds[];
+  YD_SCENE_BIND
   const int i = blockIdx.x * 64 + threadIdx.x;
   const bool valid = i < n;
   V3 ro = vof(0.0f), rd = v3(0, 0, 1);
   if (valid) { const float *p = rays + 7 * (size_t)i; ro = v3(p[0], p[1], p[2]); rd = v3(p[3], p[4], p[5]); }
   Counters c = {};
   bool bad_mat = false;
-  V3 v = radiance<MODE, false>(sc, valid, ro, rd, lds, threadIdx.x, c, bad_mat);
+  V3 v = radiance<MODE, false, 1>(sc, valid, ro, rd, lds, lds, c, bad_mat);
   if (valid) { rgb[3 * (size_t)i] = v.x; rgb[3 * (size_t)i + 1] = v.y; rgb[3 * (size_t)i + 2] = v.z; }
   const unsigned n_bad = lanes(bad_mat);
   if (n_bad && threadIdx.x == 0) atomicAdd(&ctr[CTR_BAD_MAT], (unsigned long long)n_bad);
@@ -572,29 +690,38 @@ __global__ void k_camera_rays(DScene sc, int n, const float *__restrict__ uv, fl
 // ---- launchers (called from abi_device.cpp) -------------------------------------------------------
 namespace yahr_dev {
 
-template <int MODE>
-static hipError_t launch_render_mode(const DScene &sc, const RParams &rp, int n_blocks, size_t lds_bytes,
-                                     float *out, unsigned long long *ctr, bool stats, hipStream_t st) {
-  if (stats) hipLaunchKernelGGL((k_render<MODE, true>), dim3(n_blocks), dim3(64), lds_bytes, st, sc, rp, out, ctr);
-  else hipLaunchKernelGGL((k_render<MODE, false>), dim3(n_blocks), dim3(64), lds_bytes, st, sc, rp, out, ctr);
+template <int MODE, int WPB>
+static hipError_t launch_render_mode(const DScene &sc, const RParams &rp, int n_blocks, float *out,
+                                     unsigned long long *ctr, bool stats, hipStream_t st) {
+  // per-level (w_k, D_k) stack of every thread, then (WPB > 1) the exchange area of traverse_block / block_any
+  const size_t lds_bytes = ((size_t)(sc.depth > 0 ? sc.depth : 1) * 6 * 64 * WPB +
+                            (WPB > 1 ? 12 * 64 * WPB + 2 * WPB : 0)) * sizeof(float);
+  if (stats) hipLaunchKernelGGL((k_render<MODE, true, WPB>), dim3(n_blocks), dim3(64 * WPB), lds_bytes, st, sc, sc.nodes, sc.prims, sc.normals, rp, out, ctr);
+  else hipLaunchKernelGGL((k_render<MODE, false, WPB>), dim3(n_blocks), dim3(64 * WPB), lds_bytes, st, sc, sc.nodes, sc.prims, sc.normals, rp, out, ctr);
   return hipGetLastError();
 }
 
-hipError_t launch_render(const DScene &sc, const RParams &rp, int mode, int n_blocks, float *out,
+hipError_t launch_render(const DScene &sc, const RParams &rp, int mode, bool regroup, int n_blocks, float *out,
                          unsigned long long *ctr, bool stats, hipStream_t st) {
-  const size_t lds_bytes = (size_t)(sc.depth > 0 ? sc.depth : 1) * 6 * 64 * sizeof(float);
+  if (regroup) {
+    switch (mode) {
+      case TRAV_LANE: return launch_render_mode<TRAV_LANE, YAHR_REGROUP_WAVES>(sc, rp, n_blocks, out, ctr, stats, st);
+      case TRAV_PACKET: return launch_render_mode<TRAV_PACKET, YAHR_REGROUP_WAVES>(sc, rp, n_blocks, out, ctr, stats, st);
+      default: return launch_render_mode<TRAV_ADAPTIVE, YAHR_REGROUP_WAVES>(sc, rp, n_blocks, out, ctr, stats, st);
+    }
+  }
   switch (mode) {
-    case TRAV_LANE: return launch_render_mode<TRAV_LANE>(sc, rp, n_blocks, lds_bytes, out, ctr, stats, st);
-    case TRAV_PACKET: return launch_render_mode<TRAV_PACKET>(sc, rp, n_blocks, lds_bytes, out, ctr, stats, st);
-    default: return launch_render_mode<TRAV_ADAPTIVE>(sc, rp, n_blocks, lds_bytes, out, ctr, stats, st);
+    case TRAV_LANE: return launch_render_mode<TRAV_LANE, 1>(sc, rp, n_blocks, out, ctr, stats, st);
+    case TRAV_PACKET: return launch_render_mode<TRAV_PACKET, 1>(sc, rp, n_blocks, out, ctr, stats, st);
+    default: return launch_render_mode<TRAV_ADAPTIVE, 1>(sc, rp, n_blocks, out, ctr, stats, st);
   }
 }
 
 hipError_t launch_trace(const DScene &sc, int mode, int n, const float *rays, int any_hit, int *prim_out,
                         float *t_out, hipStream_t st) {
   const int nb = (n + 63) / 64;
-  if (mode == TRAV_LANE) hipLaunchKernelGGL((k_trace<TRAV_LANE>), dim3(nb), dim3(64), 0, st, sc, n, rays, any_hit, prim_out, t_out);
-  else hipLaunchKernelGGL((k_trace<TRAV_PACKET>), dim3(nb), dim3(64), 0, st, sc, n, rays, any_hit, prim_out, t_out);
+  if (mode == TRAV_LANE) hipLaunchKernelGGL((k_trace<TRAV_LANE>), dim3(nb), dim3(64), 0, st, sc, sc.nodes, sc.prims, sc.normals, n, rays, any_hit, prim_out, t_out);
+  else hipLaunchKernelGGL((k_trace<TRAV_PACKET>), dim3(nb), dim3(64), 0, st, sc, sc.nodes, sc.prims, sc.normals, n, rays, any_hit, prim_out, t_out);
   return hipGetLastError();
 }
 
@@ -602,9 +729,9 @@ hipError_t launch_radiance(const DScene &sc, int mode, int n, const float *rays,
                            unsigned long long *ctr, hipStream_t st) {
   const int nb = (n + 63) / 64;
   const size_t lds_bytes = (size_t)(sc.depth > 0 ? sc.depth : 1) * 6 * 64 * sizeof(float);
-  if (mode == TRAV_LANE) hipLaunchKernelGGL((k_radiance<TRAV_LANE>), dim3(nb), dim3(64), lds_bytes, st, sc, n, rays, rgb, ctr);
-  else if (mode == TRAV_PACKET) hipLaunchKernelGGL((k_radiance<TRAV_PACKET>), dim3(nb), dim3(64), lds_bytes, st, sc, n, rays, rgb, ctr);
-  else hipLaunchKernelGGL((k_radiance<TRAV_ADAPTIVE>), dim3(nb), dim3(64), lds_bytes, st, sc, n, rays, rgb, ctr);
+  if (mode == TRAV_LANE) hipLaunchKernelGGL((k_radiance<TRAV_LANE>), dim3(nb), dim3(64), lds_bytes, st, sc, sc.nodes, sc.prims, sc.normals, n, rays, rgb, ctr);
+  else if (mode == TRAV_PACKET) hipLaunchKernelGGL((k_radiance<TRAV_PACKET>), dim3(nb), dim3(64), lds_bytes, st, sc, sc.nodes, sc.prims, sc.normals, n, rays, rgb, ctr);
+  else hipLaunchKernelGGL((k_radiance<TRAV_ADAPTIVE>), dim3(nb), dim3(64), lds_bytes, st, sc, sc.nodes, sc.prims, sc.normals, n, rays, rgb, ctr);
   return hipGetLastError();
 }
 

@@ -54,7 +54,7 @@ enum { CTR_PRIMARY = 0, CTR_REFLECTION, CTR_SHADOW, CTR_SHADED, CTR_BAD_MAT,
        CTR_MAX_WAVE_CYCLES = CTR_COUNT, CTR_SUM_WAVE_CYCLES, CTR_TOTAL };
 
 namespace yahr_dev {
-hipError_t launch_render(const DScene &sc, const RParams &rp, int mode, int n_blocks, float *out,
+hipError_t launch_render(const DScene &sc, const RParams &rp, int mode, bool regroup, int n_blocks, float *out,
                          unsigned long long *ctr, bool stats, hipStream_t st);
 hipError_t launch_trace(const DScene &sc, int mode, int n, const float *rays, int any_hit, int *prim_out,
                         float *t_out, hipStream_t st);

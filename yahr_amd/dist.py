@@ -66,13 +66,13 @@ class ShardPlan:
         return out[0] if single else out
 
 
-def render_sharded(render_fn, plan, rank, group=None, bufs=None):
+def render_sharded(render_fn, plan, rank, group=None, bufs=None, force_collective=False):
     """Unpipelined form: render_fn(shard, n_shards, strip_rows, out) renders this rank's strips of every frame of
     the batch into `out` ([frames, max_rows, width, 3]; rows beyond plan.rows[rank] are padding).  Returns the
     assembled images [frames, height, width, 3] on rank 0, None elsewhere.  One gather per call."""
     local, gathered, image = bufs if bufs is not None else plan.buffers(rank)
     render_fn(rank, plan.world, plan.strip_rows, local)
-    if plan.world == 1:
+    if plan.world == 1 and not force_collective:
         return local[:, : plan.height]
     dist.gather(local, gather_list=[gathered[r] for r in range(plan.world)] if rank == 0 else None, dst=0, group=group)
     if rank != 0:
@@ -85,11 +85,14 @@ class ShardPipeline:
     (on rank 0) the assembly of launch i complete while launch i+1 renders.  drain() finishes everything and
     returns the images of the LAST launch on rank 0.  Every launch is fully rendered, gathered and assembled."""
 
-    def __init__(self, plan, rank, group=None):
+    def __init__(self, plan, rank, group=None, force_collective=False):
+        # force_collective: run the gather + side-stream assembly even with a single rank (a one-rank RCCL group
+        # is the only way to exercise that path on a one-GPU box; tests/test_gpu_parity.py)
         self.plan, self.rank, self.group = plan, rank, group
+        self.collective = plan.world > 1 or force_collective
         self.slots = [plan.buffers(rank), plan.buffers(rank)]
         self.cuda = plan.device.type == "cuda"
-        self.side = torch.cuda.Stream(device=plan.device) if (self.cuda and rank == 0 and plan.world > 1) else None
+        self.side = torch.cuda.Stream(device=plan.device) if (self.cuda and rank == 0 and self.collective) else None
         self.work = [None, None]             # per slot: handle of the gather in flight
         self.done = [None, None]             # per slot (rank 0, cuda): event recorded after the slot's assembly
         self.launch = [-1, -1]               # per slot: index of the launch occupying it
@@ -130,7 +133,7 @@ class ShardPipeline:
         local, gathered, image = self.slots[slot]
         self.launch[slot] = self.n
         render_fn(self.rank, self.plan.world, self.plan.strip_rows, local)
-        if self.plan.world == 1:
+        if not self.collective:
             self.last = local[:, : self.plan.height]
             if self.on_assembled:
                 self.on_assembled(self.n, self.last)

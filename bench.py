@@ -162,8 +162,10 @@ def main():
             "hybrid": yahr_amd.TRAVERSE_HYBRID}[args.traverse]
     # frames per launch: the largest divisor of K not above the request, so that EXACTLY K frames are timed
     # (the request scales with the rank count: every rank then gets as many tiles per launch as in the 1-GPU case,
-    # so the per-launch tail stays amortised and the gathers get larger and fewer)
-    F = max(1, min(args.frames_per_launch * world, args.steps))
+    # so the per-launch tail stays amortised and the gathers get larger and fewer
+    # ... but never fewer than ~8 launches when K allows it: the gather + assembly of the LAST launch cannot hide
+    # behind a render, so it must stay a small part of the timed region)
+    F = max(1, min(args.frames_per_launch * world, max(args.frames_per_launch, args.steps // 8), args.steps))
     while args.steps % F:
         F -= 1
     n_launches = args.steps // F

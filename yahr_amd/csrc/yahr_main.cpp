@@ -9,6 +9,7 @@
 // in the status line.  Exit status: 0 on success, 1 on any error with the message on stderr, like an
 // uncaught Haskell exception.  Environment: YAHR_DEVICES=<n> limits the GPUs used (default: all),
 // YAHR_LENIENT=1 accepts the stale bundled scene.yahrr dialect, YAHR_SPP=<n> supersampling extension.
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -57,12 +58,18 @@ int main(int argc, char **argv) {
     return die("Non-exhaustive patterns in case (parallel mode \"" + mode + "\")");   // main.hs:134-137
   if (threads < 1) threads = 1;
 
+  const bool timing = std::getenv("YAHR_TIMING") && std::atoi(std::getenv("YAHR_TIMING")) != 0;
+  const auto t_start = std::chrono::steady_clock::now();
+  auto since = [&](std::chrono::steady_clock::time_point t) {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
+  };
   const char *len_env = std::getenv("YAHR_LENIENT");
   yahr_host_scene *hs = nullptr;
   if (yahr_scene_load(pos[0].c_str(), len_env && std::atoi(len_env) != 0, &hs) != YAHR_OK) return die(yahr_last_error());
   const yahr_scene *flat = yahr_scene_flat(hs);
   if (!flat) { std::string e = yahr_last_error(); yahr_scene_free(hs); return die(e); }
 
+  const double ms_load = since(t_start);               // read + parse + expand + BVH build + flatten
   int n_dev = yahr_device_count();
   if (n_dev < 1) { yahr_scene_free(hs); return die("no HIP device available (this build has no CPU path)"); }
   if (const char *e = std::getenv("YAHR_DEVICES")) { int want = std::atoi(e); if (want >= 1 && want < n_dev) n_dev = want; }
@@ -77,7 +84,9 @@ int main(int argc, char **argv) {
 
   std::vector<float> rgb((size_t)flat->width * flat->height * 3, 0.0f);
   yahr_stats st;
+  const auto t_render = std::chrono::steady_clock::now();
   int rc = yahr_render_multi(flat, n_dev, &opts, rgb.data(), &st);
+  const double ms_render = since(t_render);            // HIP start-up + upload + kernel + download
   if (rc != YAHR_OK) { std::string e = yahr_last_error(); yahr_scene_free(hs); return die(e); }
   const double rays = (double)(st.primary_rays + st.reflection_rays + st.shadow_rays);
   std::fprintf(stderr, "yahr-hip: %d x gfx950, %dx%d, %.3f ms kernel, %.1f Mpixels/s", n_dev, flat->width, flat->height,
@@ -87,9 +96,13 @@ int main(int argc, char **argv) {
   std::fprintf(stderr, "\n");
 
   if (flat->width <= 0 || flat->height <= 0) { yahr_scene_free(hs); return die("image has zero size"); }
+  const auto t_write = std::chrono::steady_clock::now();
   if (ends_with(pos[1], ".ppm")) rc = yahr_write_ppm(pos[1].c_str(), rgb.data(), flat->width, flat->height);
   else if (ends_with(pos[1], ".pfm")) rc = yahr_write_pfm(pos[1].c_str(), rgb.data(), flat->width, flat->height);
   else rc = yahr_write_png(pos[1].c_str(), rgb.data(), flat->width, flat->height);   // savePngImage (main.hs:142)
+  if (timing)
+    std::fprintf(stderr, "yahr-hip timing: load+build %.1f ms, device (init+upload+render+download) %.1f ms, encode+write %.1f ms\n",
+                 ms_load, ms_render, since(t_write));
   yahr_scene_free(hs);
   if (rc != YAHR_OK) return die(yahr_last_error());
   return 0;

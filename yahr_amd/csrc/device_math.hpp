@@ -95,11 +95,26 @@ YD bool tri_candidate(V3 p0, V3 e1, V3 e2, V3 o, V3 u, float tmax, float &t, flo
 // The same test cut in two for the packet walker (identical operations and values, only regrouped): stage 1
 // needs s, s1, the determinant and its reciprocal and yields b1 with its range test; when no lane of the
 // wavefront passes it the caller skips stage 2 (s2, t, b2, b0 and their tests) with a wave-uniform branch.
-YD bool tri_stage1(V3 p0, V3 e1, V3 e2, V3 o, V3 u, V3 &s, float &inv, float &b1) {
+//
+// Stage 0 stops before the division: det = s1.e1 and q = s1.s.  `tri_far(q, det)` -- |q| > 1.5 |det| -- PROVES
+// that b1 = fl(q * fl(1/det)) fails its range test, whatever the operands:
+//   * det = +-0: 1/det = +-inf and q != 0 (|q| > 0), so b1 = +-inf: not in [0,1];
+//   * det, q finite, det != 0: fl(1/det) is correctly rounded (relative error <= 2^-24, <= 2^-20 when 1/det is
+//     subnormal; +-inf when det is subnormal and 1/det overflows), so |q * fl(1/det)| >= 1.3 even after the
+//     subnormal rounding of 1.5|det| (worst case 5/3), and one more rounding leaves |b1| > 1.29: b1 > 1 or b1 < 0;
+//   * q = +-inf: b1 = +-inf;  q or det NaN, or det = +-inf: the comparison is false, nothing is claimed.
+// So when EVERY live lane of the wavefront is "far", the ten-instruction IEEE divide and the rest of stage 1 can
+// be skipped without changing any lane's result; otherwise stage 1 runs in full for all lanes, as before.
+YD void tri_stage0(V3 p0, V3 e1, V3 e2, V3 o, V3 u, V3 &s, float &det, float &q) {
   s = o - p0;
   const V3 s1 = cross(u, e2);
-  inv = 1.0f / dot(s1, e1);
-  b1 = dot(s1, s) * inv;
+  det = dot(s1, e1);
+  q = dot(s1, s);
+}
+YD bool tri_far(float q, float det) { return fabsf(q) > 1.5f * fabsf(det); }
+YD bool tri_stage1(float det, float q, float &inv, float &b1) {
+  inv = 1.0f / det;
+  b1 = q * inv;
   // bitwise & on purpose (here and below): the comparisons are pure, and short-circuit && makes the compiler
   // build exec-mask branches around every term
   return (b1 >= 0.0f) & (b1 <= 1.0f);

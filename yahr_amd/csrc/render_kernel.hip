@@ -136,12 +136,16 @@ YD bool test_prim_packet(const DScene &sc, int idx, const PrimRec &p, bool live,
   bool got = false;
   if (__float_as_int(p.r1.w) == 0) {                                  // wave-uniform branch
     if (STATS) c.tri += live ? 1u : 0u;
-    V3 s; float inv, b1;
-    const bool p1 = tri_stage1(xyz(p.r0), xyz(p.r1), xyz(p.r2), o, u, s, inv, b1) & live;
-    if (wany(p1)) {
-      float t, b2;
-      const bool p2 = tri_stage2(xyz(p.r1), xyz(p.r2), s, u, inv, b1, tmax, t, b2) & p1;
-      if (p2) got = tri_accept(sc, idx, u, t, b1, b2, tmax, hit);
+    V3 s; float det, q;
+    tri_stage0(xyz(p.r0), xyz(p.r1), xyz(p.r2), o, u, s, det, q);
+    if (wany(live & !tri_far(q, det))) {               // else: b1 is provably out of range on every live lane
+      float inv, b1;
+      const bool p1 = tri_stage1(det, q, inv, b1) & live;
+      if (wany(p1)) {
+        float t, b2;
+        const bool p2 = tri_stage2(xyz(p.r1), xyz(p.r2), s, u, inv, b1, tmax, t, b2) & p1;
+        if (p2) got = tri_accept(sc, idx, u, t, b1, b2, tmax, hit);
+      }
     }
   } else {
     if (STATS) c.sph += live ? 1u : 0u;

@@ -250,6 +250,23 @@ YD int wave_min_i32(int v) {
 // when no lane can produce a NaN in it.
 // Returns n when the traversal is complete, or (ADAPT only) the node index at which the wave gave up being a
 // packet: lane l then continues at max(i, wake_l) with its tmax / hit (outputs), see traverse_packet.
+// Box test of the packet walker for the lanes that are inside the current subtree (`on`): h = hit & on.
+// NaN-free form: a lane that is not `on` gets tMax = -1, so its tfar <= -1 < 0 <= tnear and the ONE float compare
+// already says "miss" -- the lane mask never has to be AND-ed in with scalar instructions, and "any lane" is the
+// vccz branch of that compare (a scalar compare on a VALU-written mask stalls the wave for the write-back).
+// Needs every lane NaN-free, also the ones that never were active: traverse_packet gives those a harmless ray.
+template <bool FAST>
+YD void packet_box(const NodeRec &nd, bool on, V3 o, V3 inv, float tmax, bool &h, bool &anyh) {
+  if (FAST) {
+    h = slab_hit_fast(xyz(nd.lo), xyz(nd.hi), o, inv, on ? tmax : -1.0f);
+    anyh = wany(h);
+  } else {
+    const bool hs = slab_hit(xyz(nd.lo), xyz(nd.hi), o, inv, tmax);
+    h = hs & on;
+    anyh = (__builtin_amdgcn_ballot_w64(hs) & __builtin_amdgcn_ballot_w64(on)) != 0ULL;
+  }
+}
+
 template <bool STATS, bool FAST, bool ADAPT, bool ANY>
 YD int packet_loop(const DScene &sc, bool active, V3 o, V3 u, V3 inv, float &tmax, Hit &hit, int &wake, Counters &c) {
   constexpr bool any_hit = ANY;                        // first-hit (shadow) mode is a compile-time property here
@@ -277,10 +294,8 @@ YD int packet_loop(const DScene &sc, bool active, V3 o, V3 u, V3 inv, float &tma
     if (b >= 0) {                                      // leaf
       PrimRec pcur = load_prim(sc, b);                 // first primitive, requested before the slab test
       // branch-free for all lanes, masked afterwards; "any lane" is decided on the two compare masks themselves
-      const bool hs = FAST ? slab_hit_fast(xyz(cur.lo), xyz(cur.hi), o, inv, tmax)
-                           : slab_hit(xyz(cur.lo), xyz(cur.hi), o, inv, tmax);
-      const bool h = hs & on;
-      const bool anyh = (__builtin_amdgcn_ballot_w64(hs) & __builtin_amdgcn_ballot_w64(on)) != 0ULL;
+      bool h, anyh;
+      packet_box<FAST>(cur, on, o, inv, tmax, h, anyh);
       if (anyh) {
         bool got = false;
         for (int k = 0; k < a; ++k) {
@@ -302,11 +317,11 @@ YD int packet_loop(const DScene &sc, bool active, V3 o, V3 u, V3 inv, float &tma
         }
       }
     } else {                                           // interior
-      const bool hs = FAST ? slab_hit_fast(xyz(cur.lo), xyz(cur.hi), o, inv, tmax)
-                           : slab_hit(xyz(cur.lo), xyz(cur.hi), o, inv, tmax);
-      const bool h = hs & on;
-      const bool anyh = (__builtin_amdgcn_ballot_w64(hs) & __builtin_amdgcn_ballot_w64(on)) != 0ULL;
-      wake = (on & !h) ? a : wake;
+      bool h, anyh;
+      packet_box<FAST>(cur, on, o, inv, tmax, h, anyh);
+      // a lane that is in this subtree and misses sleeps until the skip target.  Written as max(): a lane that
+      // is NOT in the subtree went to sleep at an enclosing node j, and skip(i) <= skip(j) = its wake
+      wake = h ? wake : (wake > a ? wake : a);
       next = anyh ? i + 1 : a;
     }
     if (next >= n) return n;
@@ -319,12 +334,13 @@ YD int packet_loop(const DScene &sc, bool active, V3 o, V3 u, V3 inv, float &tma
 // reference's tests in the reference's order, so where the hand-off happens cannot change a result.
 template <bool STATS, bool ADAPT>
 YD void traverse_packet(const DScene &sc, bool active, bool any_hit, V3 o, V3 u, float tmax, Hit &hit, Counters &c) {
-  const V3 inv = v3(1.0f / u.x, 1.0f / u.y, 1.0f / u.z);
+  V3 inv = v3(1.0f / u.x, 1.0f / u.y, 1.0f / u.z);
   hit.prim = -1; hit.t = 0.0f; hit.b1 = 0.0f; hit.b2 = 0.0f;
   const int n = sc.n_nodes;
   if (n == 0 || !wany(active)) return;
   // every node box finite (host check) and no active lane able to form 0*inf or inf-inf in the slab test?
   const bool fast = sc.boxes_finite != 0 && !wany(active & !slab_safe(o, inv));
+  if (fast && !active) { o = vof(0.0f); inv = vof(1.0f); }     // inactive lanes: NaN-free too (packet_box)
   int wake, i;
   // four copies of the loop (fast/exact slab x closest/first hit), selected once per traversal: run-time flags
   // inside the loop cost scalar instructions on every step

@@ -138,7 +138,9 @@ YD bool test_prim_packet(const DScene &sc, int idx, const PrimRec &p, bool live,
     if (STATS) c.tri += live ? 1u : 0u;
     V3 s; float det, q;
     tri_stage0(xyz(p.r0), xyz(p.r1), xyz(p.r2), o, u, s, det, q);
-    if (wany(live & !tri_far(q, det))) {               // else: b1 is provably out of range on every live lane
+    // lanes that are not live count as "far" (q = inf): one select instead of AND-ing lane masks with scalar
+    // instructions, and the branch is the vccz of the compare itself
+    if (wany(!tri_far(live ? q : __builtin_huge_valf(), det))) {   // else: b1 provably out of range on every live lane
       float inv, b1;
       const bool p1 = tri_stage1(det, q, inv, b1) & live;
       if (wany(p1)) {

@@ -47,7 +47,9 @@ using namespace yd;
 #define YAHR_WAVES_LANE 8
 #endif
 #ifndef YAHR_WAVES
-#define YAHR_WAVES 5   // swept 3..8 on the pseudo-bunny: flat within 4 % (the kernel is critical-path bound), 5 best
+// packet walker, 8-frame batches of the pseudo-bunny: 4/5/6 waves per SIMD are the same code (79 VGPRs) 0.432 ms
+// per frame; 7 (72 VGPRs, three spills in the kernel prologue/epilogue) 0.415; 8 (64 VGPRs, spills in the loops) 0.526
+#define YAHR_WAVES 7
 #endif
 // waves per workgroup when rays are regrouped between traversals (yahr_render_opts.tuning bit 2)
 #define YAHR_REGROUP_WAVES 4

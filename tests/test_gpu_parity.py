@@ -514,3 +514,64 @@ def test_random_scenes_against_the_oracle(gpu, seed):
                          cam, mats, lights, objs)
     assert_parity(d)
     assert_parity(d, modes=[yahr_amd.TRAVERSE_AUTO], spp=4, seed=seed)
+
+
+@pytest.mark.parametrize("bvh_depth", [0, 3, 16])
+def test_extreme_operands_walkers_agree(gpu, bvh_depth):
+    """Adversarial operands for the packet walker's shortcuts (NaN-free slab form, tMax = -1 for sleeping lanes, the
+    division-free `far` reject ahead of the triangle's IEEE divide): triangles and rays whose coordinates mix
+    0, subnormals, 1e-38, 1e-20, 1, 1e20 and 1e38, degenerate (zero-area, zero-edge) triangles, axis-parallel rays
+    (infinite reciprocals), overflowing products.  The lane walker runs the plain tests; the packet walker must
+    return the same primitive and the same t bit for bit, and both must equal the oracle."""
+    rng = np.random.default_rng(77 + bvh_depth)
+    mags = np.array([0.0, 1e-45, 1e-41, 1e-38, 1e-30, 1e-20, 1e-6, 1.0, 1.0, 3.0, 1e3, 1e20, 1e38], dtype=np.float64)
+
+    def extreme(shape):
+        return (rng.choice(mags, size=shape) * rng.choice([-1.0, 1.0], size=shape) * rng.uniform(0.5, 1.0, size=shape)).astype(np.float32)
+
+    objs = []
+    for i in range(160):
+        kind = i % 4
+        if kind == 0:        # ordinary triangle near the origin
+            c = rng.uniform(-2, 2, 3)
+            p = [c + rng.uniform(-1, 1, 3) for _ in range(3)]
+        elif kind == 1:      # extreme magnitudes per coordinate
+            p = [extreme(3) for _ in range(3)]
+        elif kind == 2:      # tiny triangle at an ordinary place
+            c = rng.uniform(-2, 2, 3)
+            p = [c + extreme(3) * 1e-30 for _ in range(3)]
+        else:                # degenerate: repeated vertex or collinear
+            a = rng.uniform(-2, 2, 3); b = rng.uniform(-2, 2, 3)
+            p = [a, b, a if i % 8 == 3 else a + 2.0 * (b - a)]
+        p = [tuple(np.asarray(v, dtype=np.float32).tolist()) for v in p]
+        n = tuple(rng.normal(size=3).astype(np.float32).tolist())
+        objs.append(("triangle", p[0], p[1], p[2], n, n, n, "sphere"))
+    objs.append(("sphere", (0.0, 0.0, 5.0), 1.0, "sphere"))
+    d = scenes.scene_fixed(8, 8).with_(objects=objs, bvh_depth=bvh_depth)
+    scene = d.to_scene().build()
+    ctx = yahr_amd.Context(scene, 0)
+    n_rays = 64 * 48
+    o = np.where(rng.random((n_rays, 3)) < 0.25, extreme((n_rays, 3)), rng.uniform(-4, 4, (n_rays, 3))).astype(np.float32)
+    dirs = rng.normal(size=(n_rays, 3))
+    dirs[rng.random((n_rays, 3)) < 0.08] = 0.0                 # axis-parallel components: 1/0 = inf
+    dirs = np.where(rng.random((n_rays, 3)) < 0.1, extreme((n_rays, 3)), dirs).astype(np.float32)
+    tmax = np.where(rng.random(n_rays) < 0.2, extreme(n_rays), 1e6).astype(np.float32)
+    rays = np.concatenate([o, dirs, tmax[:, None]], axis=1).astype(np.float32)
+    # whole waves of benign rays too, so that the NaN-free forms are certainly exercised
+    rays[: 64 * 16, 0:3] = rng.uniform(-4, 4, (64 * 16, 3))
+    rays[: 64 * 16, 3:6] = rng.normal(size=(64 * 16, 3)) + np.sign(rng.normal(size=(64 * 16, 3))) * 0.05
+    rays[: 64 * 16, 6] = 1e6
+    with np.errstate(all="ignore"):
+        pl, tl = ctx.trace(rays, yahr_amd.TRAVERSE_LANE)
+        pp, tp = ctx.trace(rays, yahr_amd.TRAVERSE_PACKET)
+    assert np.array_equal(pl, pp)
+    assert np.array_equal(tl.view(np.uint32), tp.view(np.uint32))
+    assert np.array_equal(ctx.occluded(rays, yahr_amd.TRAVERSE_LANE), ctx.occluded(rays, yahr_amd.TRAVERSE_PACKET))
+    assert (pl >= 0).sum() > 50                                 # the test is not vacuous
+    osc = OracleScene.from_desc(d).build()
+    for i in range(0, n_rays, 7):
+        w, t = osc.intersect(rays[i])
+        assert w == pl[i], (i, w, pl[i])
+        if w >= 0:
+            assert np.float32(t).view(np.uint32) == tl[i].view(np.uint32), i
+    ctx.close()

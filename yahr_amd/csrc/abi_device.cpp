@@ -105,10 +105,12 @@ int pick_mode(int traverse, int auto_mode = TRAV_PACKET) {
 }
 
 // AUTO policy.  Measured per frame at 1080p (ms: lane / packet / adaptive): pseudo-bunny (largest leaf 70)
-// 1.98 / 0.94 / 1.2-1.6; 200k random triangles (largest leaf 12) 5.7 / 4.5 / 4.2; 1M random triangles (largest
-// leaf 7) 11.1 / 26.5 / 10.6; 8 spheres 0.16 / 0.16 / 0.16.  Fat multi-leaves are where the packet's scalar
-// primitive broadcast shines and per-lane gathers crawl, so: largest leaf > 16 -> packet, else adaptive.
+// 1.66 / 0.69 / 1.34; 200k random triangles (largest leaf 12) 4.10 / 3.52 / 3.34; 1M random triangles (largest
+// leaf 7) 7.84 / 20.2 / 7.19; 8 spheres + 2 triangles 0.146 / 0.137 / 0.160.  Fat multi-leaves are where the
+// packet's scalar primitive broadcast shines and per-lane gathers crawl, and in a tiny scene the union of 64 paths
+// is the whole tree anyway, so: largest leaf > 16 or at most 64 primitives -> packet, else adaptive.
 int auto_mode_for(const yahr_scene *s) {
+  if (s->n_prims <= 64) return TRAV_PACKET;
   int32_t biggest = 0;
   for (int32_t i = 0; i < s->n_nodes; ++i)
     if (s->nodes[i].b >= 0 && s->nodes[i].a > biggest) biggest = s->nodes[i].a;

@@ -556,11 +556,15 @@ def test_extreme_operands_walkers_agree(gpu, bvh_depth):
     dirs[rng.random((n_rays, 3)) < 0.08] = 0.0                 # axis-parallel components: 1/0 = inf
     dirs = np.where(rng.random((n_rays, 3)) < 0.1, extreme((n_rays, 3)), dirs).astype(np.float32)
     tmax = np.where(rng.random(n_rays) < 0.2, extreme(n_rays), 1e6).astype(np.float32)
+    special = rng.random(n_rays)
+    tmax[special < 0.03] = np.nan                               # hmin(tMax, x) = x: a NaN tMax never limits a ray
+    tmax[(special >= 0.03) & (special < 0.06)] = np.inf
+    tmax[(special >= 0.06) & (special < 0.08)] = -1.0           # also the value sleeping lanes are given
     rays = np.concatenate([o, dirs, tmax[:, None]], axis=1).astype(np.float32)
     # whole waves of benign rays too, so that the NaN-free forms are certainly exercised
     rays[: 64 * 16, 0:3] = rng.uniform(-4, 4, (64 * 16, 3))
     rays[: 64 * 16, 3:6] = rng.normal(size=(64 * 16, 3)) + np.sign(rng.normal(size=(64 * 16, 3))) * 0.05
-    rays[: 64 * 16, 6] = 1e6
+    rays[: 64 * 16, 6] = np.where(rng.random(64 * 16) < 0.1, np.nan, 1e6)
     with np.errstate(all="ignore"):
         pl, tl = ctx.trace(rays, yahr_amd.TRAVERSE_LANE)
         pp, tp = ctx.trace(rays, yahr_amd.TRAVERSE_PACKET)

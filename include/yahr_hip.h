@@ -118,6 +118,9 @@ enum { YAHR_SPLIT_MIDPOINT = 0, YAHR_SPLIT_SAH = 1 };   /* Culling.hs:18 */
  * scene.yahrr dialect (PointLight with one argument, TriangleMesh without the Normals/Smooth fields). */
 int yahr_scene_load(const char *path, int lenient, yahr_host_scene **out);
 int yahr_scene_parse(const char *text, size_t len, int lenient, yahr_host_scene **out);
+/* The loader's numeric-literal conversion on its own (tests): decimal / 0x / 0o lexeme -> binary32, correctly
+ * rounded as GHC's `read :: Float` does (Scene.hs derives Read). */
+int yahr_parse_float32(const char *lexeme, size_t len, float *out);
 
 /* programmatic assembly: what a foreign host marshals instead of text */
 int yahr_scene_new(yahr_host_scene **out);

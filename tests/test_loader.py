@@ -193,3 +193,50 @@ def test_missing_file():
     with pytest.raises(yahr_amd.YahrError) as e:
         yahr_amd.Scene.load("/nonexistent/scene.yahrr")
     assert e.value.code == -3
+
+
+# ---- numeric literals: decimal -> binary32 must be CORRECTLY rounded (GHC reads a Rational, then fromRational) ----
+def _parse_f32(lexeme):
+    import ctypes as C
+    from yahr_amd import _lib
+    out = C.c_float()
+    _lib.check(_lib.lib.yahr_parse_float32(lexeme.encode(), len(lexeme), C.byref(out)))
+    return np.float32(out.value)
+
+
+def _round_to_f32(frac):
+    """correctly rounded binary32 of an exact Fraction > 0 (normal range), ties to even -- by exact comparison"""
+    from fractions import Fraction
+    f = np.float32(float(frac))                       # a nearby float (double rounding may be off by one ulp)
+    cands = sorted({float(np.nextafter(f, np.float32(0))), float(f), float(np.nextafter(f, np.float32(np.inf)))})
+    best = min(cands, key=lambda c: (abs(Fraction(c) - frac), int(np.float32(c).view(np.uint32)) & 1))
+    return np.float32(best)
+
+
+def test_float_literals_round_trip_and_round_correctly():
+    from fractions import Fraction
+    rng = np.random.default_rng(5)
+    bits = rng.integers(0x00800000, 0x7F7FFFFF, 20000, dtype=np.uint32)       # normal positive floats, all exponents
+    vals = np.concatenate([bits.view(np.float32), rng.uniform(-1000, 1000, 5000).astype(np.float32).__abs__()])
+    for v in vals:
+        for fmt in ("%.9g", "%.8e", "%.17g"):                                   # every one identifies v uniquely
+            s = fmt % float(v)
+            assert _parse_f32(s).view(np.uint32) == np.float32(v).view(np.uint32), (s, v)
+    # decimals just below / at / just above the midpoint of two adjacent floats, short enough for the fast path
+    for v in bits.view(np.float32)[:3000]:
+        up = np.nextafter(v, np.float32(np.inf))
+        mid = (Fraction(float(v)) + Fraction(float(up))) / 2
+        for digits in (9, 12, 15):
+            e = int(np.floor(np.log10(float(v))))
+            scale = Fraction(10) ** (digits - 1 - e)
+            for k in (-1, 0, 1):
+                n = int(mid * scale) + k                                        # digits-long mantissa around the midpoint
+                s = "%de%d" % (n, e - digits + 1)
+                want = _round_to_f32(Fraction(n) / scale)
+                assert _parse_f32(s).view(np.uint32) == want.view(np.uint32), (s, float(v))
+    # the exact midpoint 2^24 + 1 ties to even; a hair above it rounds up
+    assert _parse_f32("16777217") == np.float32(16777216.0)
+    assert _parse_f32("16777217.000001") == np.float32(16777218.0)
+    assert _parse_f32("0x1F") == np.float32(31) and _parse_f32("0o17") == np.float32(15)
+    assert _parse_f32("1e-45") == np.float32(1e-45) and _parse_f32("1e39") == np.float32(np.inf)
+    assert _parse_f32("0.000") == np.float32(0) and _parse_f32("000123.4500") == np.float32(123.45)

@@ -77,6 +77,7 @@ _VP = C.c_void_p
 SIGNATURES = {
     "yahr_scene_load": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(_VP)]),
     "yahr_scene_parse": (C.c_int, [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(_VP)]),
+    "yahr_parse_float32": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_float)]),
     "yahr_scene_new": (C.c_int, [C.POINTER(_VP)]),
     "yahr_scene_set_camera": (C.c_int, [_VP, C.c_float, C.c_float, C.c_float, _F3, _F3, _F3]),
     "yahr_scene_set_integrator": (C.c_int, [_VP, C.c_int32]),

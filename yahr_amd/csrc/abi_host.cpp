@@ -54,6 +54,12 @@ int yahr_scene_parse(const char *text, size_t len, int lenient, yahr_host_scene 
   });
 }
 
+int yahr_parse_float32(const char *lexeme, size_t len, float *out) {
+  if (!lexeme || !out || len == 0) { set_error("null argument"); return YAHR_E_ARG; }
+  *out = yahr::parse_float_literal(lexeme, len);
+  return YAHR_OK;
+}
+
 int yahr_scene_load(const char *path, int lenient, yahr_host_scene **out) {
   if (!path || !out) { set_error("null argument"); return YAHR_E_ARG; }
   std::ifstream f(path, std::ios::binary);

@@ -74,6 +74,8 @@ struct HostScene {
 // parser: throws ParseError
 struct ParseError { std::string msg; size_t offset; };
 std::unique_ptr<HostScene> parse_scene(const char *text, size_t len, bool lenient);
+// one numeric lexeme (decimal, hexadecimal, octal) -> binary32, correctly rounded like GHC's read (scene_parse.cpp)
+float parse_float_literal(const char *s, size_t len);
 
 // Scene.hs:61-86 (+ material resolution of main.hs:55-60): appends the expanded primitives of `o`
 void expand_object(const SceneObject &o, const std::function<int32_t(const std::string &)> &mat_of,

@@ -12,6 +12,7 @@
 //   * integer literals are accepted for Float fields; Int fields take integer literals only
 // `lenient` additionally accepts the stale dialect of the bundled scene.yahrr (SURVEY finding 2).
 #include <cerrno>
+#include <cstdint>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -21,6 +22,60 @@
 #include "host_scene.hpp"
 
 namespace yahr {
+
+// Decimal literal -> binary32, correctly rounded (what GHC's `read :: Float` yields: the literal is read as a
+// Rational and converted with fromRational).  Fast path for the common shape -- at most 15 significant digits and a
+// decimal exponent within +-22: mantissa and 10^|e| are then exact doubles, so ONE IEEE multiply or divide gives the
+// correctly rounded double d of the literal x.  float(d) equals the correctly rounded float of x unless a midpoint
+// of two adjacent floats lies between x and d; such a midpoint is itself a double (29 low mantissa bits 1000...0) and
+// |x - d| <= ulp(d)/2, so that can only happen when d IS that midpoint (its two neighbours are excluded as well,
+// for good measure).  Everything else -- long mantissas, big exponents, results outside the normal float range,
+// hexadecimal / octal forms -- goes to strtof, which is correctly rounded too but several times slower.
+static bool fast_decimal_f32(const char *s, size_t len, float &out) {
+  static const double p10[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15,
+                                 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+  uint64_t m = 0; int nd = 0, e10 = 0; size_t i = 0;
+  for (; i < len && s[i] >= '0' && s[i] <= '9'; ++i) {
+    if (nd == 0 && s[i] == '0') continue;              // leading zeros
+    if (++nd > 15) return false;
+    m = m * 10 + (uint64_t)(s[i] - '0');
+  }
+  if (i < len && s[i] == '.') {
+    for (++i; i < len && s[i] >= '0' && s[i] <= '9'; ++i) {
+      --e10;
+      if (nd == 0 && s[i] == '0') continue;
+      if (++nd > 15) return false;
+      m = m * 10 + (uint64_t)(s[i] - '0');
+    }
+  }
+  if (i < len && (s[i] == 'e' || s[i] == 'E')) {
+    ++i; bool neg = false;
+    if (i < len && (s[i] == '+' || s[i] == '-')) { neg = s[i] == '-'; ++i; }
+    int e = 0; size_t digits = 0;
+    for (; i < len && s[i] >= '0' && s[i] <= '9'; ++i, ++digits) { if (e < 10000) e = e * 10 + (s[i] - '0'); }
+    if (digits == 0) return false;
+    e10 += neg ? -e : e;
+  }
+  if (i != len) return false;                          // not a plain decimal literal
+  if (m == 0) { out = 0.0f; return true; }
+  if (e10 < -22 || e10 > 22) return false;
+  const double d = e10 >= 0 ? (double)m * p10[e10] : (double)m / p10[-e10];
+  if (!(d >= 1e-37 && d <= 1e37)) return false;        // keep clear of subnormal floats and overflow
+  uint64_t bits; std::memcpy(&bits, &d, sizeof bits);
+  const uint64_t low = bits & 0x1FFFFFFFULL;           // the 29 mantissa bits a float does not have
+  if (low >= 0x0FFFFFFFULL && low <= 0x10000001ULL) return false;
+  out = (float)d;
+  return true;
+}
+
+float parse_float_literal(const char *s, size_t len) {
+  float v;
+  if (fast_decimal_f32(s, len, v)) return v;
+  std::string z(s, len);
+  if (z.size() > 2 && z[0] == '0' && (z[1] == 'o' || z[1] == 'O')) return (float)std::strtoull(z.c_str() + 2, nullptr, 8);
+  return std::strtof(z.c_str(), nullptr);              // correctly rounded, like fromRational
+}
+
 namespace {
 
 enum class Tok { End, Ident, Number, String, Punct };
@@ -207,9 +262,7 @@ class Parser {
       Token t = next();
       float v;
       if (t.kind == Tok::Number) {
-        std::string s(text_ + t.pos, t.len);
-        if (s.size() > 2 && s[0] == '0' && (s[1] == 'o' || s[1] == 'O')) v = (float)std::strtoull(s.c_str() + 2, nullptr, 8);
-        else v = std::strtof(s.c_str(), nullptr);              // correctly rounded, like fromRational
+        v = parse_float_literal(text_ + t.pos, t.len);
       } else if (t.kind == Tok::Ident && t.len == 3 && !std::memcmp(text_ + t.pos, "NaN", 3)) {
         v = std::numeric_limits<float>::quiet_NaN();
       } else if (t.kind == Tok::Ident && t.len == 8 && !std::memcmp(text_ + t.pos, "Infinity", 8)) {

@@ -271,65 +271,82 @@ YD void packet_box(const NodeRec &nd, bool on, V3 o, V3 inv, float tmax, bool &h
   }
 }
 
+// One node step of the packet walker: `cur` is node i, the record of node i+1 is requested into `nxt` (padded
+// array: in bounds even for the last node).  Returns the index of the next node (>= n: traversal complete).
+template <bool STATS, bool FAST, bool ADAPT, bool ANY>
+YD int packet_step(const DScene &sc, const NodeRec &cur, NodeRec &nxt, int i, V3 o, V3 u, V3 inv, float &tmax, Hit &hit,
+                   int &wake, Counters &c, int &useful) {
+  constexpr bool any_hit = ANY;                        // first-hit (shadow) mode is a compile-time property here
+  const int n = sc.n_nodes;
+  const int a = __float_as_int(cur.lo.w), b = __float_as_int(cur.hi.w);
+  nxt = load_node(sc, i + 1);
+  const bool on = wake <= i;
+  if (ADAPT) useful += (int)lanes(on);
+  if (STATS) { c.box += on ? 1u : 0u; c.wave_nodes++; }
+  int next = i + 1;
+  // ONE wave-uniform branch per node; the slab test is written out in both arms on purpose (testing the
+  // leaf flag twice made the compiler carry it as a 64-bit lane mask: ~8 extra scalar instructions per step)
+  if (b >= 0) {                                        // leaf
+    PrimRec pcur = load_prim(sc, b);                   // first primitive, requested before the slab test
+    bool h, anyh;
+    packet_box<FAST>(cur, on, o, inv, tmax, h, anyh);
+    if (anyh) {
+      bool got = false;
+      for (int k = 0; k < a; ++k) {
+        const PrimRec pnext = load_prim(sc, b + k + 1);                      // prefetch (padded array)
+        if (STATS) c.wave_prims++;
+        const bool live = h & !(any_hit & got);
+        got |= test_prim_packet<STATS>(sc, b + k, pcur, live, o, u, tmax, hit, c);
+        pcur = pnext;
+      }
+      if (any_hit) {
+        if (got) wake = YD_DONE;
+        if (wany(got)) {
+          // next node any lane still needs; readfirstlane tells the compiler the minimum is wave-uniform
+          // (otherwise the loop exit looks divergent and every node load degrades to a per-lane gather)
+          const int m = __builtin_amdgcn_readfirstlane(wave_min_i32(wake));
+          if (m == YD_DONE) return n;
+          if (m > next) next = m;
+        }
+      }
+    }
+  } else {                                             // interior
+    bool h, anyh;
+    packet_box<FAST>(cur, on, o, inv, tmax, h, anyh);
+    // a lane that is in this subtree and misses sleeps until the skip target.  Written as max(): a lane that
+    // is NOT in the subtree went to sleep at an enclosing node j, and skip(i) <= skip(j) = its wake
+    wake = h ? wake : (wake > a ? wake : a);
+    next = anyh ? i + 1 : a;
+  }
+  return next;
+}
+
+// The loop body exists twice with the two node buffers swapped: a step to the next node in array order (every
+// leaf, every interior node some lane hit) finds its record already in the other buffer, without copying eight
+// SGPRs and without making the prefetch wait for the last use of the current node.
 template <bool STATS, bool FAST, bool ADAPT, bool ANY>
 YD int packet_loop(const DScene &sc, bool active, V3 o, V3 u, V3 inv, float &tmax, Hit &hit, int &wake, Counters &c) {
-  constexpr bool any_hit = ANY;                        // first-hit (shadow) mode is a compile-time property here
   const int n = sc.n_nodes;
   wake = active ? 0 : YD_DONE;
   int i = 0;                                           // wave-uniform: lives in an SGPR
   int window = YD_WINDOW, useful = 0;                  // wave-uniform
-  NodeRec cur = load_node(sc, 0);
+  NodeRec A = load_node(sc, 0), B;
   for (;;) {
     if (ADAPT) {
-      if (window == 0) {
-        if (useful < YD_WINDOW * YD_MIN_ACTIVE) return i;
-        window = YD_WINDOW; useful = 0;
-      }
+      if (window == 0) { if (useful < YD_WINDOW * YD_MIN_ACTIVE) return i; window = YD_WINDOW; useful = 0; }
       --window;
     }
-    const int a = __float_as_int(cur.lo.w), b = __float_as_int(cur.hi.w);
-    const NodeRec nseq = load_node(sc, i + 1);         // padded array: in bounds even for the last node
-    const bool on = wake <= i;
-    if (ADAPT) useful += (int)lanes(on);
-    if (STATS) { c.box += on ? 1u : 0u; c.wave_nodes++; }
-    int next = i + 1;
-    // ONE wave-uniform branch per node; the slab test is written out in both arms on purpose (testing the
-    // leaf flag twice made the compiler carry it as a 64-bit lane mask: ~8 extra scalar instructions per step)
-    if (b >= 0) {                                      // leaf
-      PrimRec pcur = load_prim(sc, b);                 // first primitive, requested before the slab test
-      // branch-free for all lanes, masked afterwards; "any lane" is decided on the two compare masks themselves
-      bool h, anyh;
-      packet_box<FAST>(cur, on, o, inv, tmax, h, anyh);
-      if (anyh) {
-        bool got = false;
-        for (int k = 0; k < a; ++k) {
-          const PrimRec pnext = load_prim(sc, b + k + 1);                    // prefetch (padded array)
-          if (STATS) c.wave_prims++;
-          const bool live = h & !(any_hit & got);
-          got |= test_prim_packet<STATS>(sc, b + k, pcur, live, o, u, tmax, hit, c);
-          pcur = pnext;
-        }
-        if (any_hit) {
-          if (got) wake = YD_DONE;
-          if (wany(got)) {
-            // next node any lane still needs; readfirstlane tells the compiler the minimum is wave-uniform
-            // (otherwise the loop exit looks divergent and every node load degrades to a per-lane gather)
-            const int m = __builtin_amdgcn_readfirstlane(wave_min_i32(wake));
-            if (m == YD_DONE) return n;
-            if (m > next) next = m;
-          }
-        }
-      }
-    } else {                                           // interior
-      bool h, anyh;
-      packet_box<FAST>(cur, on, o, inv, tmax, h, anyh);
-      // a lane that is in this subtree and misses sleeps until the skip target.  Written as max(): a lane that
-      // is NOT in the subtree went to sleep at an enclosing node j, and skip(i) <= skip(j) = its wake
-      wake = h ? wake : (wake > a ? wake : a);
-      next = anyh ? i + 1 : a;
-    }
+    int next = packet_step<STATS, FAST, ADAPT, ANY>(sc, A, B, i, o, u, inv, tmax, hit, wake, c, useful);
     if (next >= n) return n;
-    if (next == i + 1) cur = nseq; else cur = load_node(sc, next);
+    if (next != i + 1) { A = load_node(sc, next); i = next; continue; }
+    i = next;
+    if (ADAPT) {
+      if (window == 0) { if (useful < YD_WINDOW * YD_MIN_ACTIVE) return i; window = YD_WINDOW; useful = 0; }
+      --window;
+    }
+    next = packet_step<STATS, FAST, ADAPT, ANY>(sc, B, A, i, o, u, inv, tmax, hit, wake, c, useful);
+    if (next >= n) return n;
+    if (next != i + 1) A = load_node(sc, next);
     i = next;
   }
 }

@@ -287,17 +287,21 @@ YD int packet_step(const DScene &sc, const NodeRec &cur, NodeRec &nxt, int i, V3
   // ONE wave-uniform branch per node; the slab test is written out in both arms on purpose (testing the
   // leaf flag twice made the compiler carry it as a 64-bit lane mask: ~8 extra scalar instructions per step)
   if (b >= 0) {                                        // leaf
-    PrimRec pcur = load_prim(sc, b);                   // first primitive, requested before the slab test
+    PrimRec p0 = load_prim(sc, b), p1;                 // first primitive, requested before the slab test
     bool h, anyh;
     packet_box<FAST>(cur, on, o, inv, tmax, h, anyh);
     if (anyh) {
       bool got = false;
-      for (int k = 0; k < a; ++k) {
-        const PrimRec pnext = load_prim(sc, b + k + 1);                      // prefetch (padded array)
+      // two primitives per trip, the record buffers swapped: the prefetch of the next record (padded array) never
+      // has to be copied into place (12 SGPR moves per primitive otherwise)
+      for (int k = 0; k < a; k += 2) {
+        p1 = load_prim(sc, b + k + 1);
         if (STATS) c.wave_prims++;
-        const bool live = h & !(any_hit & got);
-        got |= test_prim_packet<STATS>(sc, b + k, pcur, live, o, u, tmax, hit, c);
-        pcur = pnext;
+        got |= test_prim_packet<STATS>(sc, b + k, p0, h & !(any_hit & got), o, u, tmax, hit, c);
+        if (k + 1 >= a) break;
+        p0 = load_prim(sc, b + k + 2);
+        if (STATS) c.wave_prims++;
+        got |= test_prim_packet<STATS>(sc, b + k + 1, p1, h & !(any_hit & got), o, u, tmax, hit, c);
       }
       if (any_hit) {
         if (got) wake = YD_DONE;

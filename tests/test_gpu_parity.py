@@ -579,3 +579,31 @@ def test_extreme_operands_walkers_agree(gpu, bvh_depth):
         if w >= 0:
             assert np.float32(t).view(np.uint32) == tl[i].view(np.uint32), i
     ctx.close()
+
+
+def test_render_can_be_captured_in_a_hip_graph(gpu):
+    """yahr_ctx_render is asynchronous on the caller's stream and allocation-free after the first use of a
+    configuration: capture it once, replay it, get the same bits."""
+    import torch
+    d = scenes.pseudo_bunny(160, 96, n_lon=40, n_lat=20)
+    scene = d.to_scene().build()
+    ref, _ = yahr_amd.render_image(scene)
+    ctx = yahr_amd.Context(scene, 0)
+    out = torch.zeros((2, scene.height, scene.width, 3), device="cuda:0")
+    o = yahr_amd.make_opts(frames=2)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ctx.render_into(out.data_ptr(), 0, scene.height, o, side.cuda_stream)      # warm-up outside the capture
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        ctx.render_into(out.data_ptr(), 0, scene.height, o, torch.cuda.current_stream().cuda_stream)
+    for _ in range(3):
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        for f in range(2):
+            assert np.array_equal(bits(out[f].cpu().numpy()), bits(ref)), f
+    ctx.close()

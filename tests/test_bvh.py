@@ -102,3 +102,18 @@ def test_hypothesis_random_scenes():
         d = scenes.scene_fixed(8, 8).with_(objects=objs, bvh_depth=depth, split="SurfaceAreaHeuristic" if sah else "Midpoint")
         check_against_oracle(d)
     inner()
+
+
+@pytest.mark.parametrize("split", ["Midpoint", "SurfaceAreaHeuristic"])
+def test_concurrent_subtree_build_is_the_same_tree(split, monkeypatch):
+    """Large nodes build their two subtrees concurrently and splice them (host_scene.cpp); node for node, link for
+    link and primitive for primitive the result must be the sequential build's -- and the oracle's."""
+    d = scenes.random_tris(40000, 64, 48, bvh_depth=18)
+    d.split = split
+    monkeypatch.setenv("YAHR_BUILD_PAR", "0")
+    seq = d.to_scene().build().arrays()
+    monkeypatch.setenv("YAHR_BUILD_PAR", "3")
+    par = check_against_oracle(d)
+    assert sorted(seq) == sorted(par)
+    for k in seq:
+        assert np.ascontiguousarray(seq[k]).tobytes() == np.ascontiguousarray(par[k]).tobytes(), k

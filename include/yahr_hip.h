@@ -186,7 +186,9 @@ typedef struct yahr_render_opts {
                                   bit 1: dispatch centre tile rows first (diagnostics: measured slower);
                                   bit 2 (YAHR_TUNE_REGROUP): workgroups of 4 waves (2x2 tiles) that pack their
                                   active rays into the fewest waves before every traversal (diagnostics:
-                                  same image, measured slower -- the walkers are latency bound) */
+                                  same image, measured slower -- the walkers are latency bound);
+                                  bit 3 (YAHR_TUNE_ONE_PIXEL_PER_LANE): with spp a power of two the samples of a
+                                  pixel normally sit in neighbouring lanes; this bit restores the serial loop */
   /* Frame batch: frames > 1 renders that many frames in ONE launch (tiles of all frames interleaved, so the
    * tail of one frame overlaps the others).  Frame f lands at d_rgb + f * frame_rows * width * 3 and uses camera f of
    * yahr_ctx_set_cameras (the scene camera when none were set).  0 and 1 mean a single frame. */
@@ -198,6 +200,7 @@ typedef struct yahr_render_opts {
 #define YAHR_TUNE_XCD_BANDS 1
 #define YAHR_TUNE_CENTRE_FIRST 2
 #define YAHR_TUNE_REGROUP 4
+#define YAHR_TUNE_ONE_PIXEL_PER_LANE 8   /* spp > 1: keep one pixel per lane with a serial sample loop (diagnostics) */
 
 typedef struct yahr_stats {
   uint64_t primary_rays, reflection_rays, shadow_rays;   /* rays actually cast */

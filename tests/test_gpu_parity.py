@@ -607,3 +607,30 @@ def test_render_can_be_captured_in_a_hip_graph(gpu):
         for f in range(2):
             assert np.array_equal(bits(out[f].cpu().numpy()), bits(ref)), f
     ctx.close()
+
+
+@pytest.mark.parametrize("spp", [2, 8, 32, 64, 128])
+def test_samples_in_lanes_equal_the_serial_sample_loop(gpu, spp):
+    """spp a power of two: a wave holds min(spp, 64) samples of 64 / min(spp, 64) pixels.  Same samples, same sum
+    order -- the image and every count must equal the one-pixel-per-lane form (and the oracle) exactly; ragged
+    sizes, row shards and frame batches included."""
+    import torch
+    d = scenes.pseudo_bunny(83, 45, n_lon=40, n_lat=20)
+    scene = d.to_scene().build()
+    ref, st0 = yahr_amd.render_image(scene, spp=spp, seed=9, collect_stats=True, tuning=yahr_amd.TUNE_ONE_PIXEL_PER_LANE)
+    for m in MODES:
+        img, st1 = yahr_amd.render_image(scene, spp=spp, seed=9, collect_stats=True, traverse=m)
+        assert np.array_equal(bits(img), bits(ref)), m
+        for k in ("primary_rays", "reflection_rays", "shadow_rays", "shaded_hits", "box_tests", "tri_tests", "sphere_tests"):
+            assert st0[k] == st1[k], (k, m)
+    if spp <= 8:
+        oref, ost = oracle_render(d, spp, 9)
+        assert outside_tol(ref, oref) == 0 and st0["box_tests"] == ost["box_tests"]
+    ctx = yahr_amd.Context(scene, 0)
+    part = ctx.render(n_shards=2, shard=1, strip_rows=8, spp=spp, seed=9)
+    rows = yahr_amd.shard_global_rows(scene.height, 2, 1, 8)
+    torch.cuda.synchronize()
+    assert np.array_equal(bits(part.cpu().numpy()[: len(rows)]), bits(ref[rows]))
+    batch = ctx.render(frames=2, spp=spp, seed=9).cpu().numpy()
+    assert np.array_equal(bits(batch[0]), bits(ref)) and np.array_equal(bits(batch[1]), bits(ref))
+    ctx.close()

@@ -13,7 +13,7 @@ ERR_NAMES = {-1: "YAHR_E_ARG", -2: "YAHR_E_PARSE", -3: "YAHR_E_IO", -4: "YAHR_E_
 SPLIT_MIDPOINT, SPLIT_SAH = 0, 1
 TRAVERSE_AUTO, TRAVERSE_LANE, TRAVERSE_PACKET, TRAVERSE_HYBRID = 0, 1, 2, 3
 TILES_WAVE, TILES_REFERENCE = 0, 1
-TUNE_XCD_BANDS, TUNE_CENTRE_FIRST, TUNE_REGROUP = 1, 2, 4      # yahr_render_opts.tuning bits (diagnostics)
+TUNE_XCD_BANDS, TUNE_CENTRE_FIRST, TUNE_REGROUP, TUNE_ONE_PIXEL_PER_LANE = 1, 2, 4, 8      # yahr_render_opts.tuning bits (diagnostics)
 
 
 class YahrError(RuntimeError):

@@ -288,8 +288,18 @@ int yahr_ctx_render(yahr_ctx *c, int32_t row0, int32_t row1, const yahr_render_o
       rp.strip_rows = rp.n_local_rows > 0 ? rp.n_local_rows : 1;
     }
     rp.tile_mode = 0;
-    rp.tiles_x = (c->width + 7) / 8;
-    const int tile_rows = (rp.n_local_rows + 7) / 8;
+    // samples in lanes: with spp a power of two the 64 lanes of a wave hold min(spp, 64) samples of each of
+    // 64 / min(spp, 64) neighbouring pixels (same pixels, same samples, same sum order -- only which lane traces what)
+    rp.sil_log2 = 0; rp.pw_log2 = 3;
+    if (o.spp >= 2 && (o.spp & (o.spp - 1)) == 0 && !regroup && (o.tuning & YAHR_TUNE_ONE_PIXEL_PER_LANE) == 0) {
+      int sw = o.spp < 64 ? o.spp : 64;
+      while ((1 << rp.sil_log2) < sw) ++rp.sil_log2;
+      const int p_log2 = 6 - rp.sil_log2;              // pixels per wave = 2^p_log2, block 2^pw wide, 2^(p-pw) high
+      rp.pw_log2 = (p_log2 + 1) / 2;
+    }
+    const int tile_w = 1 << rp.pw_log2, tile_h = (64 >> rp.sil_log2) >> rp.pw_log2;
+    rp.tiles_x = (c->width + tile_w - 1) / tile_w;
+    const int tile_rows = (rp.n_local_rows + tile_h - 1) / tile_h;
     rp.n_tiles = rp.tiles_x * tile_rows;
     n_blocks = ((rp.n_tiles + 7) / 8) * 8;     // the XCD swizzle needs a multiple of 8 blocks
     if (regroup) n_blocks = ((rp.tiles_x + 1) / 2) * ((tile_rows + 1) / 2);     // a workgroup owns 2x2 tiles

@@ -36,6 +36,9 @@ struct RParams {
   int spp, n_strata; unsigned seed;
   int tile_mode;           // 0: 8x8 wave tiles, 1: reference squareBatches windows
   int xcd_swizzle;
+  // samples in lanes (tile_mode 0, spp a power of two >= 2): a wavefront holds 2^sil_log2 samples of each of
+  // 64 >> sil_log2 pixels (a 2^pw_log2 wide block) instead of one sample of 64 pixels; 0 = one pixel per lane
+  int sil_log2, pw_log2;
   const int4 *windows;     // tile_mode 1: {x0,y0,x1,y1}, {p0,batch,0,0} per 64-pixel chunk
   // frame batch: one launch renders `frames` frames; block b -> (tile b / frames, frame b % frames), so the
   // same tile of all frames is adjacent in dispatch order.  Frame f writes at out + f * frame_stride floats

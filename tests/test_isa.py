@@ -91,11 +91,13 @@ def test_register_budget_and_no_scratch(asm):
             continue
         assert m["vgpr_spill_count"] <= 8, m
         lines = kernel_body(asm, k).split("\n")
-        loops = [i for i, l in enumerate(lines) if "Loop Header: Depth=" in l]
-        inner = [i for i, l in enumerate(lines) if "Inner Loop Header" in l]
-        assert loops and inner
-        # the traversal loops end a few hundred lines after the last inner-loop header (shading follows)
-        scratch = [i for i, l in enumerate(lines) if "scratch_" in l and loops[0] <= i <= inner[-1]]
+        # the traversal loops: from the first depth-3 loop header (node loop; the primitive loops are depth 4) to
+        # the depth-2 inner loop that follows them (the fold of the radiance levels)
+        d3 = [i for i, l in enumerate(lines) if "Loop Header: Depth=3" in l]
+        assert d3
+        after = [i for i, l in enumerate(lines) if "Inner Loop Header: Depth=2" in l and i > d3[-1]]
+        assert after
+        scratch = [i for i, l in enumerate(lines) if "scratch_" in l and d3[0] <= i <= after[0]]
         assert not scratch, (k, scratch[:4])
     # lane / adaptive walkers (gather-latency bound): built for all 8 wave slots of a SIMD, i.e. 64 VGPRs; the
     # values that do not fit (radiance state that is dead during a traversal) are spilled around the loops

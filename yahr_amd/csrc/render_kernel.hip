@@ -666,33 +666,28 @@ void k_render(DScene sc_in, YD_SCENE_PARAMS, RParams rp, float *__restrict__ out
     row = (size_t)gv;
   }
   V3 acc = vof(0.0f);
-  if (rp.sil_log2 == 0) {
-    for (int s = 0; s < rp.spp; ++s) {
-      float du = 0.0f, dv = 0.0f;                      // spp == 1: the integer pixel corner (main.hs:73)
-      if (rp.spp > 1) sample_offset(u, gv, s, rp.n_strata, rp.seed, du, dv);
-      V3 ro, rd;
-      camera_ray(cam, (float)u + du, (float)gv + dv, ro, rd);
-      const V3 v = radiance<MODE, STATS, WPB>(sc, valid, ro, rd, lds, xch, c, bad_mat);
+  // One sample loop for both lane layouts (ONE radiance call site: it is the whole kernel, inlined).
+  //  * sil_log2 == 0: a lane is a pixel and takes its samples one after the other;
+  //  * samples in lanes: the wave's rays go through a few neighbouring pixels (ONE pixel at 64 spp), so the packet
+  //    walks hardly more than a single ray's path.  The pixel is still the sum of its samples IN SAMPLE ORDER
+  //    (left fold from 0): the samples of a round are parked in LDS and the pixel's first lane adds them up.
+  const int sw = 1 << rp.sil_log2, j0 = lane & (sw - 1);
+  for (int s0 = 0; s0 < rp.spp; s0 += sw) {
+    float du = 0.0f, dv = 0.0f;                        // spp == 1: the integer pixel corner (main.hs:73)
+    if (rp.spp > 1) sample_offset(u, gv, s0 + j0, rp.n_strata, rp.seed, du, dv);
+    V3 ro, rd;
+    camera_ray(cam, (float)u + du, (float)gv + dv, ro, rd);
+    const V3 v = radiance<MODE, STATS, WPB>(sc, valid, ro, rd, lds, xch, c, bad_mat);
+    if (rp.sil_log2 == 0) {
       acc = (rp.spp > 1) ? acc + v : v;
-    }
-  } else {
-    // Samples in lanes: the wave's rays go through a few neighbouring pixels (ONE pixel at 64 spp), so the packet
-    // walks hardly more than a single ray's path.  The pixel is still the sum of its samples IN SAMPLE ORDER
-    // (left fold from 0): the samples of a round are parked in LDS and the pixel's first lane adds them up.
-    const int sw = 1 << rp.sil_log2, j0 = lane & (sw - 1);
-    for (int s0 = 0; s0 < rp.spp; s0 += sw) {
-      float du, dv;
-      sample_offset(u, gv, s0 + j0, rp.n_strata, rp.seed, du, dv);
-      V3 ro, rd;
-      camera_ray(cam, (float)u + du, (float)gv + dv, ro, rd);
-      const V3 v = radiance<MODE, STATS, WPB>(sc, valid, ro, rd, lds, xch, c, bad_mat);
+    } else {
       float *park = lds;                               // the radiance stack of this wave is free again
       park[lane] = v.x; park[64 + lane] = v.y; park[128 + lane] = v.z;
       if (j0 == 0)
         for (int k = 0; k < sw; ++k) acc = acc + v3(park[lane + k], park[64 + lane + k], park[128 + lane + k]);
     }
-    valid = valid && j0 == 0;                          // the pixel's first lane stores it
   }
+  if (rp.sil_log2 != 0) valid = valid && j0 == 0;      // the pixel's first lane stores it
   if (rp.spp > 1) acc = scale(1.0f / (float)rp.spp, acc);
   if (valid) {
     float *px = out + (row * rp.width + u) * 3;          // samplesToImage: w*v+u (main.hs:100)

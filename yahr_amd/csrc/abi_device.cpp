@@ -105,12 +105,14 @@ int pick_mode(int traverse, int auto_mode = TRAV_PACKET) {
 }
 
 // AUTO policy.  Measured per frame at 1080p (ms: lane / packet / adaptive): pseudo-bunny (largest leaf 70)
-// 1.66 / 0.69 / 1.34; 200k random triangles (largest leaf 12) 4.10 / 3.52 / 3.34; 1M random triangles (largest
-// leaf 7) 7.84 / 20.2 / 7.19; 8 spheres + 2 triangles 0.146 / 0.137 / 0.160.  Fat multi-leaves are where the
-// packet's scalar primitive broadcast shines and per-lane gathers crawl, and in a tiny scene the union of 64 paths
-// is the whole tree anyway, so: largest leaf > 16 or at most 64 primitives -> packet, else adaptive.
+// 1.66 / 0.68 / 1.34; 200k random triangles (BVH 16: 0.13 M nodes, largest leaf 12) 4.10 / 2.92 / 3.39 (16 spp:
+// - / 13.0 / 17.0); 1M random triangles (BVH 20: 2 M nodes, largest leaf 7) 7.72 / 20.2 / 7.24 (16 spp: 76 / 73 / 63);
+// 8 spheres + 2 triangles 0.146 / 0.137 / 0.160.  The packet walker wins wherever the union of 64 paths stays
+// small: fat multi-leaves (scalar primitive broadcast), tiny scenes, moderately deep trees.  Only a very deep
+// tree of thin leaves under incoherent secondary rays makes the union explode: more than half a million nodes
+// and no leaf above 16 primitives -> adaptive, everything else -> packet.
 int auto_mode_for(const yahr_scene *s) {
-  if (s->n_prims <= 64) return TRAV_PACKET;
+  if (s->n_prims <= 64 || s->n_nodes <= 500000) return TRAV_PACKET;
   int32_t biggest = 0;
   for (int32_t i = 0; i < s->n_nodes; ++i)
     if (s->nodes[i].b >= 0 && s->nodes[i].a > biggest) biggest = s->nodes[i].a;

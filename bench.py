@@ -202,7 +202,8 @@ def main():
     primary_per_step = int(my[0].item())
 
     # ---- warmup (>= W frames), then EXACTLY K timed steps (= K/F launches) bracketed by barrier + synchronize
-    for _ in range((args.warmup + F - 1) // F):
+    # (at least three launches, whatever W: the first launches after start-up run at ramping clocks)
+    for _ in range(max(3, (args.warmup + F - 1) // F)):
         pipe.submit(render_fn)
     pipe.drain()
     torch.cuda.synchronize()

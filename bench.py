@@ -6,19 +6,27 @@
 
 A "step" is one render of the whole frame: every rank renders its row strips (scene resident in its HBM
 before the timed region), a gather over RCCL brings the strips to rank 0, rank 0 scatters them into the
-image.  Total work is fixed as N grows ("scaling": "strong").  Frames are rendered in batches of F per kernel
-launch (--frames-per-launch, default 8; tiles of the F frames interleaved) with ONE gather per launch: a single
-1080p frame is bounded by the serial chain of its heaviest tile (~0.9 ms), not by throughput, so the tail of one
-frame is overlapped with the other frames of the batch.  K steps = K/F launches; every frame is fully rendered,
-gathered and assembled inside the timed region.  Workload: BASELINE.json configs[2] -- the
-metric's own configuration -- with the documented stand-in mesh: the reference ships no bunny mesh
-(SURVEY finding 3), so the scene is the procedural 69,696-triangle "pseudo-bunny" of yahr_amd/scenes.py on the
-+-1000 plane, 1 light, 1 spp, WhittedIntegrator depth 2, BVH 16 Midpoint.
+image.  Total work is fixed as N grows ("scaling": "strong").
+
+Frames are rendered F = 8 per kernel launch (x the rank count; tiles of the F frames interleaved) with ONE
+gather per launch: a single 1080p frame is bounded by the serial chain of its heaviest tile, not by
+throughput, so the tail of one frame overlaps the other frames of the batch.  The F frames of a launch have F
+DISTINCT cameras (a small orbit around the model), so no frame shares rays with another.  A block of K steps
+is floor(K/F) launches of F frames plus one launch of K mod F frames: exactly K frames, whatever K.  Because a
+block of K = 20 frames lasts only ~9 ms, the block is REPEATED R times inside the timed region (R chosen so
+that the region lasts >= ~1 s, printed as "repeats"); ms_per_step = timed region / (R * K).  Every frame is
+fully rendered, gathered and assembled inside the timed region.
+
+Workload: BASELINE.json configs[2] -- the metric's own configuration -- with the documented stand-in mesh: the
+reference ships no bunny mesh (SURVEY finding 3), so the scene is the procedural 69,696-triangle
+"pseudo-bunny" of yahr_amd/scenes.py on the +-1000 plane, 1 light, 1 spp, WhittedIntegrator depth 2, BVH 16
+Midpoint.
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field's definition).
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -26,6 +34,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [ROOT]
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -34,21 +43,46 @@ from yahr_amd import scenes
 from yahr_amd.dist import ShardPipeline, ShardPlan
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling ~6290 GB/s
+# vector-instruction issue ceiling of the chip from the microarch guide: 256 CUs x 4 SIMD-32, a wave64 VALU
+# instruction occupies its SIMD for 2 cycles, 2.4 GHz  ->  1024 * 2.4e9 / 2 = 1228.8 G wave-instructions/s
+VALU_PEAK_GINST_S = 1228.8
 
+# workload -> (scene description, text, point the camera orbit turns around)
 WORKLOADS = {
     "bunny": lambda: (scenes.pseudo_bunny(1920, 1080, depth=2),
                       "pseudo-bunny (procedural stand-in, 69,696 tris + 2-tri plane), 1920x1080, 1 spp, "
-                      "Whitted depth 2, BVH 16 Midpoint, 1 point light"),
+                      "Whitted depth 2, BVH 16 Midpoint, 1 point light", (0.2, 0.9, 0.0)),
     "spheres": lambda: (scenes.spheres8(1920, 1080, depth=1),
-                        "8 spheres + plane + 2 point lights, 1920x1080, 1 spp, Whitted depth 1, BVH 16 Midpoint"),
-    "bunny_small": lambda: (scenes.pseudo_bunny(480, 270, depth=2), "pseudo-bunny 480x270 (smoke size)"),
+                        "8 spheres + plane + 2 point lights, 1920x1080, 1 spp, Whitted depth 1, BVH 16 Midpoint",
+                        (0.0, -1.2, 15.0)),
+    "bunny_small": lambda: (scenes.pseudo_bunny(480, 270, depth=2), "pseudo-bunny 480x270 (smoke size)", (0.2, 0.9, 0.0)),
     # BASELINE.json configs[3] and [4]; spp > 1 and "stratified" are build extensions (sampler)
     "bunny4k": lambda: (scenes.pseudo_bunny(3840, 2160, depth=4),
-                        "pseudo-bunny 3840x2160, 64 spp stratified, Whitted depth 4 (primary + 3 reflection segments)"),
+                        "pseudo-bunny 3840x2160, 64 spp stratified, Whitted depth 4 (primary + 3 reflection segments)",
+                        (0.2, 0.9, 0.0)),
     "tris1m": lambda: (scenes.random_tris(1_000_000, 1920, 1080, depth=2, bvh_depth=20),
-                       "1M random triangles (splitmix64 seed 0x5EED), 1920x1080, 16 spp, Whitted depth 2, BVH 20 Midpoint"),
+                       "1M random triangles (splitmix64 seed 0x5EED), 1920x1080, 16 spp, Whitted depth 2, BVH 20 Midpoint",
+                       (0.0, 0.0, 0.0)),
 }
 WORKLOAD_SPP = {"bunny4k": 64, "tris1m": 16}
+ORBIT_STEP_DEG = 1.5           # angle between neighbouring cameras of a frame batch
+
+
+def orbit_cameras(cam, target, n):
+    """n cameras on a horizontal circle around `target` through the scene camera's position, ORBIT_STEP_DEG
+    apart and centred on the scene camera, each looking at the target like the scene camera does (same offset
+    between its look direction and the direction to the target).  Rows of yahr_ctx_set_cameras."""
+    pos = np.array(cam["pos"], dtype=np.float64)
+    look = np.array(cam["look"], dtype=np.float64)
+    tgt = np.array(target, dtype=np.float64)
+    rows = []
+    for i in range(n):
+        a = math.radians((i - (n - 1) / 2.0) * ORBIT_STEP_DEG)
+        c, s = math.cos(a), math.sin(a)
+        rot = np.array([[c, 0.0, s], [0.0, 1.0, 0.0], [-s, 0.0, c]])
+        p = tgt + rot @ (pos - tgt)
+        rows.append([cam["imW"], cam["imH"], cam["focal"], *(rot @ look), *cam["up"], *p])
+    return np.array(rows, dtype=np.float32)
 
 
 def algorithmic_bytes(st, n_lights, n_pixels):
@@ -60,8 +94,8 @@ def algorithmic_bytes(st, n_lights, n_pixels):
 
 def cpu_baseline(desc, cores, spp=1, min_cpu_seconds=10.0):
     """The oracle (CPU restatement of the reference, kind "port": the Haskell reference cannot be built here)
-    timed on the host cores over the same workload: whole frames, repeated until ~min_cpu_seconds of CPU work
-    (spp == 1), or a bounded sample of evenly spaced 8-row strips of one frame (supersampled workloads)."""
+    timed on the host cores over the same workload: whole frames (scene camera), repeated until ~min_cpu_seconds
+    of CPU work (spp == 1), or a bounded sample of evenly spaced 8-row strips of one frame (supersampled)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_py                      # the checker, timed beside the product; never part of the product path
     osc = oracle_py.OracleScene.from_desc(desc).build()
@@ -91,35 +125,19 @@ def cpu_baseline(desc, cores, spp=1, min_cpu_seconds=10.0):
         reps += 1
         rays += st["primary_rays"] + st["reflection_rays"] + st["shadow_rays"]
     return dict(value=round(rays / wall / 1e6, 3), unit="Mrays/s", cores=cores, kind="port",
-                sample=f"{reps} full frame(s) of the same workload, render only (scene build excluded), "
+                sample=f"{reps} full frame(s) of the same workload (scene camera), render only (scene build excluded), "
                        f"{wall:.2f} s wall on {cores} threads over the reference's squareBatches tiles",
                 mpixels_per_s=round(reps * st["primary_rays"] / wall / 1e6, 3)), st
 
 
-def load_traffic(workload):
-    """HBM bytes per launch from rocprofv3 PMC passes (profiles/, collected separately as the microarch guide
-    prescribes; FETCH_SIZE already doubled for gfx950).  None when no profile matches this workload."""
-    p = os.path.join(ROOT, "profiles", "traffic_latest.json")
+def load_profile(workload):
+    """Per-frame counter figures of the committed rocprofv3 PMC profile of this workload (profiles/
+    traffic_latest.json, written by tools/pmc_to_traffic.py from separate --pmc passes), or None."""
     try:
-        j = json.load(open(p))
-        if j.get("workload") == workload:
-            return j.get("hbm_bytes_per_launch")
+        j = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
+        return j if j.get("workload") == workload else None
     except (OSError, ValueError):
-        pass
-    return None
-
-
-def load_valu_profile(workload, frames_per_launch):
-    """(VALU wave-instructions per launch, measured VALU issue peak in G instr/s) from the committed PMC profile,
-    valid for the profiled configuration only (8 frames per launch, 1 GPU); else None."""
-    p = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    try:
-        j = json.load(open(p))
-        if j.get("workload") == workload and frames_per_launch == 8 and "valu_insts_per_launch" in j:
-            return j["valu_insts_per_launch"], j["valu_issue_peak_ginst_s"]
-    except (OSError, ValueError):
-        pass
-    return None
+        return None
 
 
 def main():
@@ -130,7 +148,11 @@ def main():
     ap.add_argument("--workload", default="bunny", choices=sorted(WORKLOADS))
     ap.add_argument("--traverse", default="auto", choices=["auto", "lane", "packet", "hybrid"])
     ap.add_argument("--strip-rows", type=int, default=8)
-    ap.add_argument("--frames-per-launch", type=int, default=8)
+    ap.add_argument("--frames-per-launch", type=int, default=8, help="per rank; a launch holds this x ranks frames")
+    ap.add_argument("--repeats", type=int, default=0, help="repeats of the K-step block inside the timed region; 0 = "
+                                                           "as many as make the region last --min-seconds")
+    ap.add_argument("--min-seconds", type=float, default=1.0)
+    ap.add_argument("--same-camera", action="store_true", help="every frame of a batch uses the scene camera (diagnostics)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true",
                     help="finish gather + assembly of a launch before the next render starts (diagnostics)")
@@ -152,133 +174,194 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    desc, workload_name = WORKLOADS[args.workload]()
+    desc, workload_name, target = WORKLOADS[args.workload]()
     t0 = time.perf_counter()
     scene = desc.to_scene().build()
     build_s = time.perf_counter() - t0
     ctx = yahr_amd.Context(scene, local_rank)
     w, h = scene.width, scene.height
+    K = args.steps
     trav = {"auto": yahr_amd.TRAVERSE_AUTO, "lane": yahr_amd.TRAVERSE_LANE, "packet": yahr_amd.TRAVERSE_PACKET,
             "hybrid": yahr_amd.TRAVERSE_HYBRID}[args.traverse]
-    # frames per launch: the largest divisor of K not above the request, so that EXACTLY K frames are timed
-    # (the request scales with the rank count: every rank then gets as many tiles per launch as in the 1-GPU case,
-    # so the per-launch tail stays amortised and the gathers get larger and fewer
-    # ... but never fewer than ~8 launches when K allows it: the gather + assembly of the LAST launch cannot hide
-    # behind a render, so it must stay a small part of the timed region)
-    F = max(1, min(args.frames_per_launch * world, max(args.frames_per_launch, args.steps // 8), args.steps))
-    while args.steps % F:
-        F -= 1
-    n_launches = args.steps // F
+    # frames per launch: 8 per rank (every rank then gets as many tiles per launch as in the 1-GPU case, so the
+    # per-launch tail stays amortised and the gathers get larger and fewer), never more than K
+    F = max(1, min(args.frames_per_launch * world, K))
+    n_full, f_tail = K // F, K % F
+    if not args.same_camera:
+        ctx.set_cameras(orbit_cameras(desc.camera, target, F))
     plan = ShardPlan(h, w, world, args.strip_rows, device=dev, frames=F)
     # double-buffered: gather + assembly of launch i overlap the render of launch i+1 (yahr_amd/dist.py)
     pipe = ShardPipeline(plan, rank)
     bufs = pipe.slots[0]
     stream = torch.cuda.current_stream()
     spp = WORKLOAD_SPP.get(args.workload, 1)
-    o_run = yahr_amd.make_opts(traverse=trav, n_shards=world, shard=rank, strip_rows=args.strip_rows, frames=F,
-                               frame_rows=plan.max_rows, spp=spp)
-    o_stat = yahr_amd.make_opts(traverse=trav, n_shards=world, shard=rank, strip_rows=args.strip_rows, collect_stats=True,
-                                spp=spp)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_launches)]
-    step_no = [-1]
+    shard = dict(traverse=trav, n_shards=world, shard=rank, strip_rows=args.strip_rows, spp=spp, frame_rows=plan.max_rows)
+    o_full = yahr_amd.make_opts(frames=F, **shard)
+    o_tail = yahr_amd.make_opts(frames=f_tail, **shard) if f_tail else None
+    timed_ev = []                            # HIP event pairs around the F-frame launches of the timed region
 
-    def render_fn(shard, n_shards, strip_rows, out):
-        # launched on torch's current stream, so torch.cuda.Event brackets exactly this kernel
-        i = step_no[0]
-        if i >= 0:
-            ev[i][0].record(stream)
-        ctx.render_into(out.data_ptr(), 0, h, o_run, stream.cuda_stream)
-        if i >= 0:
-            ev[i][1].record(stream)
+    def render_with(opts, timed):
+        def render_fn(shard_, n_shards_, strip_rows_, out):
+            # launched on torch's current stream, so the torch.cuda.Event pair brackets exactly this kernel
+            if timed:
+                e = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                e[0].record(stream)
+            ctx.render_into(out.data_ptr(), 0, h, opts, stream.cuda_stream)
+            if timed:
+                e[1].record(stream)
+                timed_ev.append(e)
+        return render_fn
 
-    # ---- one counted single-frame launch per rank (deterministic counters; not timed)
-    ctx.render_into(bufs[0].data_ptr(), 0, h, o_stat, stream.cuda_stream)
-    torch.cuda.synchronize()
-    st = ctx.stats()
-    my = torch.tensor([st["primary_rays"], st["reflection_rays"], st["shadow_rays"]], dtype=torch.int64, device=dev)
-    if world > 1:
-        dist.all_reduce(my)
-    rays_per_step = int(my.sum().item())
-    primary_per_step = int(my[0].item())
+    def block(timed):
+        """one block = exactly K frames"""
+        for _ in range(n_full):
+            pipe.submit(render_with(o_full, timed))
+            if args.no_overlap:
+                pipe.drain()
+        if o_tail is not None:
+            pipe.submit(render_with(o_tail, False))
+            if args.no_overlap:
+                pipe.drain()
 
-    # ---- warmup (>= W frames), then EXACTLY K timed steps (= K/F launches) bracketed by barrier + synchronize
-    # (at least three launches, whatever W: the first launches after start-up run at ramping clocks)
+    # ---- counted launches per rank (deterministic counters; not timed): the F-frame launch, the tail launch
+    def counted(frames):
+        o = yahr_amd.make_opts(frames=frames, collect_stats=True, **shard)
+        ctx.render_into(bufs[0].data_ptr(), 0, h, o, stream.cuda_stream)
+        torch.cuda.synchronize()
+        return ctx.stats()
+    st_full = counted(F)
+    st_tail = counted(f_tail) if f_tail else None
+
+    def ray_counts(st):
+        t = torch.tensor([st["primary_rays"], st["reflection_rays"], st["shadow_rays"]], dtype=torch.int64, device=dev)
+        if world > 1:
+            dist.all_reduce(t)
+        return int(t.sum().item()), int(t[0].item())
+    rays_full, prim_full = ray_counts(st_full)
+    rays_tail, prim_tail = ray_counts(st_tail) if st_tail else (0, 0)
+    rays_per_block = n_full * rays_full + rays_tail
+    prim_per_block = n_full * prim_full + prim_tail
+
+    # ---- warmup: >= W frames and at least three launches (the first launches after start-up run at ramping
+    # clocks), then one calibration block to choose R
     for _ in range(max(3, (args.warmup + F - 1) // F)):
-        pipe.submit(render_fn)
+        pipe.submit(render_with(o_full, False))
     pipe.drain()
+    torch.cuda.synchronize()
+    R = args.repeats
+    if R <= 0:
+        t0 = time.perf_counter()
+        block(False)
+        pipe.drain()
+        torch.cuda.synchronize()
+        tb = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tb, op=dist.ReduceOp.MAX)      # every rank must agree on R
+        R = max(1, min(100000, int(math.ceil(args.min_seconds / max(float(tb.item()), 1e-6)))))
+
+    # ---- timed region: R blocks of EXACTLY K steps, bracketed by barrier + synchronize on both sides
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    img = None
-    for i in range(n_launches):
-        step_no[0] = i
-        pipe.submit(render_fn)
-        if args.no_overlap:
-            pipe.drain()
+    for _ in range(R):
+        block(True)
     img = pipe.drain()                      # every launch rendered, gathered and assembled before the clock stops
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    step_no[0] = -1
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
-    kern_ms = [a.elapsed_time(b) for a, b in ev]
-    kernel_ms_avg = sum(kern_ms) / len(kern_ms)
+    kern_ms = [a.elapsed_time(b) for a, b in timed_ev]
+    kernel_ms_avg = sum(kern_ms) / len(kern_ms) if kern_ms else float("nan")
+
+    # ---- a lone frame per launch (the scene camera): bound by its longest wave, reported beside the batch figure
+    o_one = yahr_amd.make_opts(frames=1, **shard)
+    one_ev = []
+    for i in range(24):
+        e = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        e[0].record(stream)
+        ctx.render_into(bufs[0].data_ptr(), 0, h, o_one, stream.cuda_stream)
+        e[1].record(stream)
+        if i >= 4:
+            one_ev.append(e)
+    torch.cuda.synchronize()
+    single_ms = sorted(a.elapsed_time(b) for a, b in one_ev)[len(one_ev) // 2]
 
     if rank == 0:
         assert img is not None and tuple(img.shape) == (F, h, w, 3)
-        checksum = float(img[F - 1].double().sum().item())
-        n_px = w * h
-        # roofline of the dominant (only) kernel on this rank: algorithmic bytes of ITS launch (F frames of this
-        # rank's strips) / its average duration
-        alg = F * algorithmic_bytes(st, scene.n_lights, yahr_amd.shard_rows(h, world, rank, args.strip_rows) * w)
-        achieved = alg / (kernel_ms_avg * 1e-3) / 1e9
+        checksum = float(img[0].double().sum().item())
+        n_steps = R * K
+        my_px = yahr_amd.shard_rows(h, world, rank, args.strip_rows) * w
+        alg = algorithmic_bytes(st_full, scene.n_lights, F * my_px)      # of this rank's F-frame launch
+        prof = load_profile(args.workload) if world == 1 else None
+        roof = {"kernel": "k_render", "kernel_ms_avg": round(kernel_ms_avg, 4), "frames_per_launch": F,
+                "launches_timed": len(kern_ms)}
+        if prof is not None and kern_ms:
+            # what the counters say bounds the kernel: vector-instruction issue (DESIGN.md section 4).  Instruction
+            # counts are deterministic per frame, so the profile's per-frame figures (mean over the cameras of the
+            # orbit) scale to any number of frames per launch.
+            valu = int(prof["valu_insts_per_frame"] * F)
+            g = valu / (kernel_ms_avg * 1e-3) / 1e9
+            traffic = int(prof["hbm_bytes_per_frame"] * F)
+            roof.update({
+                "bound": "valu-issue", "achieved": round(g, 1), "peak": VALU_PEAK_GINST_S, "unit": "G wave-instr/s",
+                "frac": round(g / VALU_PEAK_GINST_S, 4),
+                "peak_source": "MI355X_MICROARCH.md: 1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 VALU instruction",
+                "frac_of_measured_issue_peak": round(g / prof["valu_issue_peak_measured_ginst_s"], 4),
+                "measured_issue_peak": prof["valu_issue_peak_measured_ginst_s"],
+                "valu_insts_per_launch": valu,
+                "traffic": traffic,
+                "hbm": {"achieved": round(traffic / (kernel_ms_avg * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(traffic / (kernel_ms_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        "source": "rocprofv3 FETCH_SIZE (x2, gfx950) + WRITE_SIZE per frame x frames per launch"},
+                "profile": prof.get("source", "profiles/traffic_latest.json"),
+            })
+        else:
+            roof.update({"bound": "valu-issue", "achieved": None, "peak": VALU_PEAK_GINST_S, "unit": "G wave-instr/s",
+                         "frac": None, "traffic": None,
+                         "note": "no committed PMC profile for this workload / rank count (profiles/traffic_latest.json)"})
+        # SURVEY 8(d)'s algorithmic-byte model, kept as a FIELD: the records are served by scalar broadcasts and L2,
+        # so this is not HBM traffic and is not a fraction of anything (DESIGN.md section 4)
+        roof["algorithmic_bytes_per_launch"] = alg
+        roof["algorithmic_gbs"] = round(alg / (kernel_ms_avg * 1e-3) / 1e9, 1) if kern_ms else None
         out = {
             "metric": "Mrays/s (primary + reflection + shadow rays cast), bunny scene 1920x1080" if args.workload == "bunny"
                       else f"Mrays/s, {args.workload}",
-            "value": round(rays_per_step * args.steps / elapsed / 1e6, 2),
+            "value": round(rays_per_block * R / elapsed / 1e6, 2),
             "unit": "Mrays/s",
-            "mpixels_per_s": round(primary_per_step / spp * args.steps / elapsed / 1e6, 2),
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "mpixels_per_s": round(prim_per_block / spp * R / elapsed / 1e6, 2),
+            "n_gpus": world, "steps": K, "warmup": args.warmup, "repeats": R, "frames_timed": n_steps,
+            "timed_region_s": round(elapsed, 4),
+            "ms_per_step": round(elapsed / n_steps * 1e3, 4),
+            "single_frame_ms": round(single_ms, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32",
             "data": ("synthetic (procedural pseudo-bunny: no bunny mesh ships with the reference)"
                      if args.workload.startswith("bunny") else "synthetic (generated scene, yahr_amd/scenes.py)"),
-            "config": {"workload": workload_name, "rays_per_frame": rays_per_step, "spp": spp, "traverse": args.traverse,
+            "config": {"workload": workload_name, "rays_per_frame": round(rays_per_block / K, 1), "spp": spp,
+                       "traverse": args.traverse,
+                       "cameras": ("the scene camera for every frame" if args.same_camera else
+                                   f"{F} distinct cameras per launch, an orbit of {ORBIT_STEP_DEG} degree steps around the model"),
                        "sharding": f"{world} rank(s), strips of {args.strip_rows} rows round-robin, one gather to rank 0 per "
                                    "launch, gather+assembly of launch i overlapped with the render of launch i+1",
-                       "frames_per_launch": F, "launches": n_launches,
+                       "frames_per_launch": F, "launches_per_block": n_full + (1 if f_tail else 0),
+                       "tail_launch_frames": f_tail,
                        "host_scene_build_s": round(build_s, 3)},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": load_traffic(args.workload),
-                         "kernel": "k_render", "kernel_ms_avg": round(kernel_ms_avg, 4), "frames_per_launch": F,
-                         "algorithmic_bytes_per_launch": alg,
-                         "note": "algorithmic bytes = per-ray tests x record sizes (SURVEY 8d), counted by the kernel's "
-                                 "own counters (== oracle, first-hit shadow rays); node/primitive records are served "
-                                 "from SGPR broadcasts and L2, so HBM traffic is far below this figure and frac can "
-                                 "exceed what a DRAM stream could reach -- the kernel is VALU/latency bound"},
+            "roofline": roof,
             "image_checksum": checksum,
         }
-        vp = load_valu_profile(args.workload, F) if world == 1 else None
-        if vp is not None:
-            # what actually bounds the kernel: vector-instruction issue
-            g = vp[0] / (kernel_ms_avg * 1e-3) / 1e9
-            out["roofline"]["valu_issue"] = {"achieved": round(g, 1), "peak": vp[1], "unit": "G wave-instr/s",
-                                             "frac": round(g / vp[1], 4),
-                                             "source": "SQ_INSTS_VALU of profiles/ / live launch time; peak measured by tools/ubench/valu_rate.hip"}
         if world == 1 and not args.no_cpu_baseline:
             cores = min(16, os.cpu_count() or 1)
             cb, ost = cpu_baseline(desc, cores, spp)
             out["cpu_baseline"] = cb
             if ost is not None:
-                out["roofline"]["algorithmic_bytes_reference_order"] = algorithmic_bytes(ost, scene.n_lights, n_px)
+                roof["algorithmic_bytes_reference_order_per_frame"] = algorithmic_bytes(ost, scene.n_lights, w * h)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

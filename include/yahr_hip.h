@@ -215,6 +215,11 @@ typedef struct yahr_stats {
 
 void yahr_default_opts(yahr_render_opts *o);
 int yahr_device_count(void);
+/* free / total bytes of a device's HBM (hipMemGetInfo after a device synchronise) */
+int yahr_device_mem_info(int device, uint64_t *free_bytes, uint64_t *total_bytes);
+/* Test hook: make the nth device allocation from now on (1 = the next one) fail with out-of-memory, once;
+ * 0 disarms.  Used to check that no error path of this library leaks device memory. */
+void yahr_debug_fail_alloc(int32_t nth);
 
 /* Upload a flattened scene to `device` (index as seen by this process).  The context owns device memory. */
 int yahr_ctx_create(const yahr_scene *scene, int device, yahr_ctx **out);

@@ -381,9 +381,19 @@ def test_frame_batch_equals_single_frames(gpu):
     ctx.close()
 
 
-# ---- the largest BASELINE scene: 1M random triangles, deep BVH (config 5) at a size the oracle finishes quickly ----
-def test_one_million_triangles_deep_bvh(gpu):
-    d = scenes.random_tris(1_000_000, 240, 135, depth=2, bvh_depth=20)
+# ---- the largest BASELINE scene: 1M random triangles, deep BVH (config 5) at sizes the oracle finishes quickly ----
+COUNT_KEYS = ("primary_rays", "reflection_rays", "shadow_rays", "shaded_hits", "box_tests", "tri_tests", "sphere_tests")
+
+
+@pytest.fixture(scope="module")
+def tris1m():
+    """1 M random triangles, BVH 20 Midpoint (BASELINE config 5) with a small image; the camera size is the only
+    thing the tests below vary, so the 1 M-primitive host scene is described once."""
+    return scenes.random_tris(1_000_000, 240, 135, depth=2, bvh_depth=20)
+
+
+def test_one_million_triangles_deep_bvh(gpu, tris1m):
+    d = tris1m
     scene = d.to_scene().build()
     assert scene.flat.contents.n_prims == 1_000_000 and scene.flat.contents.n_nodes > 1_000_000
     ref, ost = oracle_render(d)
@@ -397,6 +407,72 @@ def test_one_million_triangles_deep_bvh(gpu):
     for m in imgs:
         assert np.array_equal(bits(imgs[m]), bits(imgs[MODES[0]]))
     assert (ref.sum(axis=2) > 0).mean() > 0.2
+
+
+def test_config5_one_million_triangles_16spp_vs_oracle(gpu, tris1m):
+    """BASELINE config 5 on its own parameters -- 1 M triangles, BVH 20 Midpoint, Whitted depth 2, 16 spp stratified,
+    seed 0 -- at 120x68 so that the oracle finishes in seconds: every walker and AUTO against the oracle, pixels
+    within tolerance, every count equal, walkers bitwise equal to each other."""
+    d = tris1m.with_camera(imW=120, imH=68)
+    img, ref = assert_parity(d, modes=MODES + [yahr_amd.TRAVERSE_AUTO], spp=16, seed=0)
+    assert (ref.sum(axis=2) > 0).mean() > 0.2
+
+
+def test_config4_bunny_depth4_64spp_vs_oracle(gpu):
+    """BASELINE config 4 on its own parameters -- pseudo-bunny (69,696 triangles), Whitted depth 4 (primary + 3
+    reflection segments), 64 spp stratified, seed 0 -- at 96x54: every walker and AUTO against the oracle."""
+    d = scenes.pseudo_bunny(96, 54, depth=4)
+    img, ref = assert_parity(d, modes=MODES + [yahr_amd.TRAVERSE_AUTO], spp=64, seed=0)
+    assert (ref.sum(axis=2) > 0).mean() > 0.3
+
+
+def _shard_assembly_equals(ctx, scene, img, world, **kw):
+    import torch
+    from yahr_amd.dist import ShardPlan
+    plan = ShardPlan(scene.height, scene.width, world, 8, device="cuda:0")
+    parts = [ctx.render(n_shards=world, shard=r, strip_rows=8, **kw) for r in range(world)]
+    out = plan.assemble(parts)
+    torch.cuda.synchronize()
+    return np.array_equal(bits(out.cpu().numpy()), bits(img))
+
+
+def test_config4_full_size_properties(gpu):
+    """config 4 at its full size, 3840x2160 x 64 spp x depth 4 (the oracle would need hours): size-independent
+    properties -- idempotence, walker independence, 8-shard assembly bitwise, and oracle parity on a strip of rows."""
+    d = scenes.pseudo_bunny(3840, 2160, depth=4)
+    scene = d.to_scene().build()
+    ctx = yahr_amd.Context(scene, 0)
+    kw = dict(spp=64, seed=0)
+    img = ctx.render(**kw).cpu().numpy()
+    assert np.array_equal(bits(ctx.render(**kw).cpu().numpy()), bits(img))                 # idempotence
+    assert np.array_equal(bits(ctx.render(traverse=yahr_amd.TRAVERSE_HYBRID, **kw).cpu().numpy()), bits(img))
+    assert _shard_assembly_equals(ctx, scene, img, 8, **kw)
+    lit = (img.sum(axis=2) > 0).mean()
+    assert 0.3 < lit < 0.95 and np.isfinite(img).all()
+    # the oracle on 2 rows through the bunny (2 x 3840 px x 64 spp), same sampler: row ranges are bit-identical to
+    # the rows of the full render (test_row_ranges_and_ragged_sizes), so this pins full-size pixels to the oracle
+    r0 = 1200
+    ref, _ = OracleScene.from_desc(d).build().render_rows(r0, r0 + 2, spp=64, seed=0, threads=NTHREADS)
+    assert outside_tol(img[r0:r0 + 2], ref) == 0
+    ctx.close()
+
+
+def test_config5_full_size_properties(gpu, tris1m):
+    """config 5 at its full size, 1920x1080 x 16 spp: idempotence, walker independence (all three), 8-shard
+    assembly bitwise, and oracle parity on a strip of rows."""
+    d = tris1m.with_camera(imW=1920, imH=1080)
+    scene = d.to_scene().build()
+    ctx = yahr_amd.Context(scene, 0)
+    kw = dict(spp=16, seed=0)
+    img = ctx.render(**kw).cpu().numpy()
+    assert np.array_equal(bits(ctx.render(**kw).cpu().numpy()), bits(img))
+    for m in MODES:
+        assert np.array_equal(bits(ctx.render(traverse=m, **kw).cpu().numpy()), bits(img)), m
+    assert _shard_assembly_equals(ctx, scene, img, 8, **kw)
+    r0 = 540
+    ref, _ = OracleScene.from_desc(d).build().render_rows(r0, r0 + 2, spp=16, seed=0, threads=NTHREADS)
+    assert outside_tol(img[r0:r0 + 2], ref) == 0
+    ctx.close()
 
 
 def test_rccl_gather_pipeline_one_rank(gpu, tmp_path):
@@ -623,9 +699,10 @@ def test_samples_in_lanes_equal_the_serial_sample_loop(gpu, spp):
         assert np.array_equal(bits(img), bits(ref)), m
         for k in ("primary_rays", "reflection_rays", "shadow_rays", "shaded_hits", "box_tests", "tri_tests", "sphere_tests"):
             assert st0[k] == st1[k], (k, m)
-    if spp <= 8:
-        oref, ost = oracle_render(d, spp, 9)
-        assert outside_tol(ref, oref) == 0 and st0["box_tests"] == ost["box_tests"]
+    oref, ost = oracle_render(d, spp, 9)
+    assert outside_tol(ref, oref) == 0
+    for k in COUNT_KEYS:
+        assert st0[k] == ost[k], k
     ctx = yahr_amd.Context(scene, 0)
     part = ctx.render(n_shards=2, shard=1, strip_rows=8, spp=spp, seed=9)
     rows = yahr_amd.shard_global_rows(scene.height, 2, 1, 8)
@@ -634,3 +711,52 @@ def test_samples_in_lanes_equal_the_serial_sample_loop(gpu, spp):
     batch = ctx.render(frames=2, spp=spp, seed=9).cpu().numpy()
     assert np.array_equal(bits(batch[0]), bits(ref)) and np.array_equal(bits(batch[1]), bits(ref))
     ctx.close()
+
+
+def test_error_paths_do_not_leak_device_memory(gpu):
+    """Every device allocation of the library can be made to fail (yahr_debug_fail_alloc); whichever one does, the
+    call must return YAHR_E_NOMEM and the device must have as much free memory afterwards as before."""
+    d = scenes.random_tris(200_000, 64, 36, bvh_depth=16)              # ~35 MB of scene arrays: a leak would show
+    scene = d.to_scene().build()
+    L = yahr_amd.lib
+    rays = np.zeros((1_000_000, 7), dtype=np.float32)
+    rays[:, 5] = 1.0
+    rays[:, 6] = 1e6
+    uv = np.zeros((1_000_000, 2), dtype=np.float32)
+    slack = 4 << 20                                                     # allocator granularity
+
+    def free_now():
+        return yahr_amd.device_mem_info(0)[0]
+    ctx = yahr_amd.Context(scene, 0)                                    # warm-up: the runtime's own lazy allocations
+    ctx.trace(rays[:64]); ctx.radiance(rays[:64]); ctx.camera_rays(uv[:64]); ctx.render().cpu()
+    ctx.close()
+    free0 = free_now()
+    try:
+        for nth in range(1, 8):                                         # nodes, prims, normals, mats, lights, counters, cold
+            L.yahr_debug_fail_alloc(nth)
+            with pytest.raises(yahr_amd.YahrError) as e:
+                yahr_amd.Context(scene, 0)
+            assert e.value.code == -5, (nth, str(e.value))
+            assert abs(free_now() - free0) <= slack, nth
+        L.yahr_debug_fail_alloc(8)                                      # beyond the last allocation: create succeeds
+        ctx = yahr_amd.Context(scene, 0)
+        L.yahr_debug_fail_alloc(0)
+        free1 = free_now()
+        assert free0 - free1 > 30 << 20
+        for fn, arg, n_alloc in ((ctx.trace, rays, 3), (ctx.occluded, rays, 3), (ctx.radiance, rays, 2), (ctx.camera_rays, uv, 2)):
+            for nth in range(1, n_alloc + 1):
+                L.yahr_debug_fail_alloc(nth)
+                with pytest.raises(yahr_amd.YahrError) as e:
+                    fn(arg)
+                assert e.value.code == -5
+                assert abs(free_now() - free1) <= slack, (fn.__name__, nth)
+        L.yahr_debug_fail_alloc(8)                                      # one-shot render: its image buffer (8th) fails
+        with pytest.raises(yahr_amd.YahrError):
+            yahr_amd.render_image(scene)
+        assert abs(free_now() - free1) <= slack
+        prim, _ = ctx.trace(rays[:4096])                                # and the context is still usable
+        assert prim.shape == (4096,)
+        ctx.close()
+        assert abs(free_now() - free0) <= slack
+    finally:
+        L.yahr_debug_fail_alloc(0)

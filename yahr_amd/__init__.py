@@ -40,6 +40,13 @@ def device_count():
     return int(lib.yahr_device_count())
 
 
+def device_mem_info(device=0):
+    """(free, total) bytes of a device's HBM"""
+    f, t = C.c_uint64(), C.c_uint64()
+    check(lib.yahr_device_mem_info(device, C.byref(f), C.byref(t)))
+    return int(f.value), int(t.value)
+
+
 def batch_window(w, h, num, count):
     """Sampling.batchWindow (Sampling.hs:9-21) -> (x0, y0, x1, y1)."""
     out = (C.c_int32 * 4)()

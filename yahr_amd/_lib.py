@@ -98,6 +98,8 @@ SIGNATURES = {
     "yahr_n_batches": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
     "yahr_default_opts": (None, [C.POINTER(RenderOpts)]),
     "yahr_device_count": (C.c_int, []),
+    "yahr_device_mem_info": (C.c_int, [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "yahr_debug_fail_alloc": (None, [C.c_int32]),
     "yahr_ctx_create": (C.c_int, [C.POINTER(FlatScene), C.c_int, C.POINTER(_VP)]),
     "yahr_ctx_destroy": (None, [_VP]),
     "yahr_shard_rows": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),

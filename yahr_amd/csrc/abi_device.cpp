@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <string>
@@ -40,9 +41,41 @@ namespace {
     hipError_t e_ = (expr);                                                                \
     if (e_ != hipSuccess) {                                                                \
       set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                        \
-      return (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice) ? YAHR_E_NODEVICE : YAHR_E_HIP; \
+      return (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice) ? YAHR_E_NODEVICE                \
+             : e_ == hipErrorOutOfMemory ? YAHR_E_NOMEM : YAHR_E_HIP;                                  \
     }                                                                                      \
   } while (0)
+
+// ---- ownership helpers: every early return (HIP_TRY) must release what the function acquired ----
+// Device allocations of this file go through dev_alloc so that tests can make the k-th one fail
+// (yahr_debug_fail_alloc) and check with yahr_device_mem_info that no error path leaks.
+std::atomic<int> g_fail_alloc_countdown{0};
+hipError_t dev_alloc(void **p, size_t bytes) {
+  *p = nullptr;
+  int k = g_fail_alloc_countdown.load();
+  while (k > 0 && !g_fail_alloc_countdown.compare_exchange_weak(k, k - 1)) {}
+  if (k == 1) return hipErrorOutOfMemory;                 // the injected failure
+  return hipMalloc(p, bytes);
+}
+struct DevMem {                                           // one device allocation, freed on scope exit
+  void *p = nullptr;
+  DevMem() = default;
+  DevMem(const DevMem &) = delete;
+  DevMem &operator=(const DevMem &) = delete;
+  ~DevMem() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t bytes) { return dev_alloc(&p, bytes); }
+  template <class T> T *as() const { return static_cast<T *>(p); }
+};
+struct ScopedEvent {
+  hipEvent_t e = nullptr;
+  ~ScopedEvent() { if (e) (void)hipEventDestroy(e); }
+};
+struct CtxOwner {                                         // destroys a half-built context unless released
+  yahr_ctx *c;
+  explicit CtxOwner(yahr_ctx *c_) : c(c_) {}
+  ~CtxOwner() { if (c) yahr_ctx_destroy(c); }
+  yahr_ctx *release() { yahr_ctx *r = c; c = nullptr; return r; }
+};
 
 int check_scene(const yahr_scene *s) {
   if (!s) { set_error("null scene"); return YAHR_E_ARG; }
@@ -75,8 +108,8 @@ int check_scene(const yahr_scene *s) {
 
 // copies `bytes` and appends `pad` zero bytes (one padding record: the kernel prefetches "the next record")
 int upload(void **dst, const void *src, size_t bytes, size_t pad = 64) {
-  *dst = nullptr;
-  HIP_TRY(hipMalloc(dst, bytes + pad));
+  // *dst belongs to the context being built: on failure its owner (CtxOwner) frees it
+  HIP_TRY(dev_alloc(dst, bytes + pad));
   HIP_TRY(hipMemset((char *)*dst + bytes, 0, pad));
   if (src && bytes) HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
   return YAHR_OK;
@@ -135,6 +168,21 @@ int yahr_device_count(void) {
   return n;
 }
 
+int yahr_device_mem_info(int device, uint64_t *free_bytes, uint64_t *total_bytes) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { set_error("no HIP device available (libyahr_hip has no CPU fallback)"); return YAHR_E_NODEVICE; }
+  if (device < 0 || device >= ndev) { set_error("device index out of range"); return YAHR_E_NODEVICE; }
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipDeviceSynchronize());
+  size_t f = 0, t = 0;
+  HIP_TRY(hipMemGetInfo(&f, &t));
+  if (free_bytes) *free_bytes = f;
+  if (total_bytes) *total_bytes = t;
+  return YAHR_OK;
+}
+
+void yahr_debug_fail_alloc(int32_t nth) { g_fail_alloc_countdown.store(nth > 0 ? nth : 0); }
+
 int32_t yahr_shard_rows(int32_t height, int32_t n_shards, int32_t shard, int32_t strip_rows) {
   if (n_shards <= 1) return height;
   if (strip_rows <= 0 || shard < 0 || shard >= n_shards) return 0;
@@ -166,24 +214,23 @@ int yahr_ctx_create(const yahr_scene *s, int device, yahr_ctx **out) {
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
     set_error(std::string("device is ") + prop.gcnArchName + ", this library carries gfx950 code only"); return YAHR_E_NODEVICE;
   }
-  auto *c = new yahr_ctx();
+  CtxOwner own(new yahr_ctx());                           // every return below destroys it, except the last
+  yahr_ctx *c = own.c;
   c->device = device; c->width = s->width; c->height = s->height;
-  hipEvent_t u0, u1;
-  HIP_TRY(hipEventCreate(&u0)); HIP_TRY(hipEventCreate(&u1));
-  HIP_TRY(hipEventRecord(u0, nullptr));
+  ScopedEvent u0, u1;
+  HIP_TRY(hipEventCreate(&u0.e)); HIP_TRY(hipEventCreate(&u1.e));
+  HIP_TRY(hipEventRecord(u0.e, nullptr));
   if ((rc = upload(&c->d_nodes, s->nodes, sizeof(yahr_node) * (size_t)s->n_nodes)) ||
       (rc = upload(&c->d_prims, s->prims, sizeof(yahr_prim) * (size_t)s->n_prims)) ||
       (rc = upload(&c->d_normals, s->normals, sizeof(yahr_prim_normals) * (size_t)s->n_prims)) ||
       (rc = upload(&c->d_mats, s->mats, sizeof(yahr_material) * (size_t)s->n_mats)) ||
       (rc = upload(&c->d_lights, s->lights, sizeof(yahr_light) * (size_t)s->n_lights)) ||
-      (rc = upload((void **)&c->d_ctr, nullptr, sizeof(unsigned long long) * CTR_TOTAL))) {
-    yahr_ctx_destroy(c); return rc;
-  }
+      (rc = upload((void **)&c->d_ctr, nullptr, sizeof(unsigned long long) * CTR_TOTAL)))
+    return rc;
   HIP_TRY(hipMemset(c->d_ctr, 0, sizeof(unsigned long long) * CTR_TOTAL));
-  HIP_TRY(hipEventRecord(u1, nullptr));
-  HIP_TRY(hipEventSynchronize(u1));
-  float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, u0, u1)); c->upload_ms = ms;
-  hipEventDestroy(u0); hipEventDestroy(u1);
+  HIP_TRY(hipEventRecord(u1.e, nullptr));
+  HIP_TRY(hipEventSynchronize(u1.e));
+  float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, u0.e, u1.e)); c->upload_ms = ms;
   HIP_TRY(hipEventCreate(&c->ev0)); HIP_TRY(hipEventCreate(&c->ev1));
   DCold cold{};
   cold.mats = (const float4 *)c->d_mats; cold.lights = (const float4 *)c->d_lights;
@@ -191,7 +238,7 @@ int yahr_ctx_create(const yahr_scene *s, int device, yahr_ctx **out) {
   std::memcpy(cold.vtf, s->cam_vtf, sizeof cold.vtf);
   cold.focal = s->focal;
   c->cold_host = cold;
-  if ((rc = upload(&c->d_cold, &cold, sizeof cold))) { yahr_ctx_destroy(c); return rc; }
+  if ((rc = upload(&c->d_cold, &cold, sizeof cold))) return rc;
   DScene &d = c->ds;
   d.nodes = (const float4 *)c->d_nodes; d.prims = (const float4 *)c->d_prims; d.normals = (const float4 *)c->d_normals;
   d.cold = (const DCold *)c->d_cold;
@@ -203,7 +250,7 @@ int yahr_ctx_create(const yahr_scene *s, int device, yahr_ctx **out) {
     for (int k = 0; k < 3; ++k)
       if (!std::isfinite(s->nodes[i].lo[k]) || !std::isfinite(s->nodes[i].hi[k]) || !(s->nodes[i].lo[k] <= s->nodes[i].hi[k]))
         d.boxes_finite = 0;
-  *out = c;
+  *out = own.release();
   return YAHR_OK;
 }
 
@@ -227,7 +274,7 @@ static int ensure_row_order(yahr_ctx *c, int n_rows) {
   const double mid = 0.5 * (n_rows - 1);
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return std::fabs(a - mid) < std::fabs(b - mid); });
   if (c->d_row_order) { HIP_TRY(hipFree(c->d_row_order)); c->d_row_order = nullptr; }
-  HIP_TRY(hipMalloc((void **)&c->d_row_order, sizeof(int) * (size_t)(n_rows + 1)));
+  HIP_TRY(dev_alloc((void **)&c->d_row_order, sizeof(int) * (size_t)(n_rows + 1)));
   HIP_TRY(hipMemcpy(c->d_row_order, order.data(), sizeof(int) * (size_t)n_rows, hipMemcpyHostToDevice));
   c->row_order_n = n_rows;
   return YAHR_OK;
@@ -247,7 +294,7 @@ static int ensure_windows(yahr_ctx *c, int n_batches) {
     }
   }
   if (c->d_windows) { HIP_TRY(hipFree(c->d_windows)); c->d_windows = nullptr; }
-  HIP_TRY(hipMalloc((void **)&c->d_windows, sizeof(int4) * (win.size() + 2)));
+  HIP_TRY(dev_alloc((void **)&c->d_windows, sizeof(int4) * (win.size() + 2)));
   if (!win.empty()) HIP_TRY(hipMemcpy(c->d_windows, win.data(), sizeof(int4) * win.size(), hipMemcpyHostToDevice));
   c->n_windows = n_batches; c->n_chunks = (int)(win.size() / 2); c->windows_w = c->width; c->windows_h = c->height;
   return YAHR_OK;
@@ -352,7 +399,7 @@ int yahr_ctx_set_cameras(yahr_ctx *c, int32_t n, const float *cams) {
     camera_origin(tf, blocks[(size_t)i].origin);
     blocks[(size_t)i].focal = cam.focal;
   }
-  HIP_TRY(hipMalloc((void **)&c->d_cams, sizeof(DCold) * (size_t)n));
+  HIP_TRY(dev_alloc((void **)&c->d_cams, sizeof(DCold) * (size_t)n));
   HIP_TRY(hipMemcpy(c->d_cams, blocks.data(), sizeof(DCold) * (size_t)n, hipMemcpyHostToDevice));
   c->n_cams = n;
   return YAHR_OK;
@@ -384,27 +431,25 @@ static int ray_query(yahr_ctx *c, int32_t n, const float *rays, int which, int t
   if (!c || n < 0 || (n && !rays)) { set_error("bad ray query arguments"); return YAHR_E_ARG; }
   if (n == 0) return YAHR_OK;
   HIP_TRY(hipSetDevice(c->device));
-  float *d_rays = nullptr; int *d_i = nullptr; float *d_f = nullptr;
-  HIP_TRY(hipMalloc((void **)&d_rays, sizeof(float) * 7 * (size_t)n));
-  HIP_TRY(hipMemcpy(d_rays, rays, sizeof(float) * 7 * (size_t)n, hipMemcpyHostToDevice));
+  DevMem d_rays, d_i, d_f;                               // freed on every return
+  HIP_TRY(d_rays.alloc(sizeof(float) * 7 * (size_t)n));
+  HIP_TRY(hipMemcpy(d_rays.p, rays, sizeof(float) * 7 * (size_t)n, hipMemcpyHostToDevice));
   int mode = pick_mode(traverse, c->auto_mode);
-  int rc = YAHR_OK;
   if (which == 2) {
-    HIP_TRY(hipMalloc((void **)&d_f, sizeof(float) * 3 * (size_t)n));
-    HIP_TRY(yahr_dev::launch_radiance(c->ds, mode, n, d_rays, d_f, c->d_ctr, nullptr));
+    HIP_TRY(d_f.alloc(sizeof(float) * 3 * (size_t)n));
+    HIP_TRY(yahr_dev::launch_radiance(c->ds, mode, n, d_rays.as<float>(), d_f.as<float>(), c->d_ctr, nullptr));
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(fout, d_f, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(fout, d_f.p, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost));
   } else {
     if (mode == TRAV_ADAPTIVE) mode = TRAV_PACKET;
-    HIP_TRY(hipMalloc((void **)&d_i, sizeof(int) * (size_t)n));
-    HIP_TRY(hipMalloc((void **)&d_f, sizeof(float) * (size_t)n));
-    HIP_TRY(yahr_dev::launch_trace(c->ds, mode, n, d_rays, which == 1, d_i, d_f, nullptr));
+    HIP_TRY(d_i.alloc(sizeof(int) * (size_t)n));
+    HIP_TRY(d_f.alloc(sizeof(float) * (size_t)n));
+    HIP_TRY(yahr_dev::launch_trace(c->ds, mode, n, d_rays.as<float>(), which == 1, d_i.as<int>(), d_f.as<float>(), nullptr));
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(iout, d_i, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
-    if (fout) HIP_TRY(hipMemcpy(fout, d_f, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(iout, d_i.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+    if (fout) HIP_TRY(hipMemcpy(fout, d_f.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
   }
-  (void)hipFree(d_rays); (void)hipFree(d_i); (void)hipFree(d_f);
-  return rc;
+  return YAHR_OK;
 }
 
 int yahr_ctx_trace(yahr_ctx *c, int32_t n, const float *rays, int32_t traverse, int32_t *prim_orig, float *t) {
@@ -425,14 +470,13 @@ int yahr_ctx_camera_rays(yahr_ctx *c, int32_t n, const float *uv, float *rays) {
   if (!c || n < 0 || (n && (!uv || !rays))) { set_error("bad arguments"); return YAHR_E_ARG; }
   if (n == 0) return YAHR_OK;
   HIP_TRY(hipSetDevice(c->device));
-  float *d_uv = nullptr, *d_rays = nullptr;
-  HIP_TRY(hipMalloc((void **)&d_uv, sizeof(float) * 2 * (size_t)n));
-  HIP_TRY(hipMalloc((void **)&d_rays, sizeof(float) * 7 * (size_t)n));
-  HIP_TRY(hipMemcpy(d_uv, uv, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice));
-  HIP_TRY(yahr_dev::launch_camera_rays(c->ds, n, d_uv, d_rays, nullptr));
+  DevMem d_uv, d_rays;
+  HIP_TRY(d_uv.alloc(sizeof(float) * 2 * (size_t)n));
+  HIP_TRY(d_rays.alloc(sizeof(float) * 7 * (size_t)n));
+  HIP_TRY(hipMemcpy(d_uv.p, uv, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice));
+  HIP_TRY(yahr_dev::launch_camera_rays(c->ds, n, d_uv.as<float>(), d_rays.as<float>(), nullptr));
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(rays, d_rays, sizeof(float) * 7 * (size_t)n, hipMemcpyDeviceToHost));
-  (void)hipFree(d_uv); (void)hipFree(d_rays);
+  HIP_TRY(hipMemcpy(rays, d_rays.p, sizeof(float) * 7 * (size_t)n, hipMemcpyDeviceToHost));
   return YAHR_OK;
 }
 
@@ -448,7 +492,7 @@ int yahr_render_rows(const yahr_scene *scene, int32_t row0, int32_t row1, int de
   float *d_rgb = nullptr;
   auto fail = [&](int code) { if (d_rgb) (void)hipFree(d_rgb); yahr_ctx_destroy(c); return code; };
   if (bytes) {
-    if (hipMalloc((void **)&d_rgb, bytes) != hipSuccess) { set_error("hipMalloc(image) failed"); return fail(YAHR_E_NOMEM); }
+    if (dev_alloc((void **)&d_rgb, bytes) != hipSuccess) { set_error("hipMalloc(image) failed"); return fail(YAHR_E_NOMEM); }
     if (hipMemset(d_rgb, 0, bytes) != hipSuccess) { set_error("hipMemset failed"); return fail(YAHR_E_HIP); }
     rc = yahr_ctx_render(c, row0, row1, &o, d_rgb, nullptr);
     if (rc) return fail(rc);

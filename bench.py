@@ -135,7 +135,7 @@ def load_profile(workload):
     traffic_latest.json, written by tools/pmc_to_traffic.py from separate --pmc passes), or None."""
     try:
         j = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
-        return j if j.get("workload") == workload else None
+        return j if j.get("workload") == workload and "valu_insts_per_frame" in j else None
     except (OSError, ValueError):
         return None
 

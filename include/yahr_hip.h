@@ -19,6 +19,7 @@
  *                            (derived-Read grammar), expand, BVH build -> produces (1)
  *   3. yahr_ctx              a scene resident in one GPU's HBM + render launches on a HIP stream
  *   4. one-shot conveniences yahr_render_rows / yahr_render_multi (host buffers in, host image out)
+ *   4b. yahr_multi           all GPUs of the node from one process: resident scenes, one RCCL / peer-DMA gather per frame
  *
  * Conventions: return 0 (YAHR_OK) on success, negative code otherwise; yahr_last_error() gives the message
  * (thread-local).  Inputs are caller-owned and read-only for the duration of the call.  A yahr_ctx is
@@ -257,8 +258,32 @@ int yahr_ctx_camera_rays(yahr_ctx *ctx, int32_t n, const float *uv, float *rays)
 /* rgb_out: (rows rendered)*width*3 floats on the HOST. */
 int yahr_render_rows(const yahr_scene *scene, int32_t row0, int32_t row1, int device,
                      const yahr_render_opts *opts, float *rgb_out, yahr_stats *stats_or_null);
-/* whole image on n_devices GPUs of this process (strips dealt round-robin, assembled on the host).
- * The multi-process / RCCL form of the same sharding is driven from the host language (see bench.py). */
+/* ---------------------------------------------------------------------------------------------
+ * 4b. Multi-GPU: one process, every GPU of the node  (replaces renderEval / renderPar, main.hs:75-96)
+ * ------------------------------------------------------------------------------------------- */
+
+/* The scene is resident in the HBM of each device (one context per device, created once); the image is cut into
+ * strips of strip_rows rows dealt round-robin to the devices; each device renders its strips on its own stream and
+ * ONE exchange step per frame brings them over xGMI to device 0, where the image is assembled, followed by one
+ * device-to-host copy.  Transports of the exchange step: */
+enum {
+  YAHR_GATHER_AUTO = 0,   /* RCCL if librccl can be loaded (lazily, on first use), else PEER; nothing with 1 device */
+  YAHR_GATHER_RCCL = 1,   /* grouped ncclSend/ncclRecv (ncclCommInitAll, single process) + strided placement on device 0 */
+  YAHR_GATHER_PEER = 2,   /* one strided peer DMA per device (hipMemcpy2DAsync) straight into place on device 0 */
+  YAHR_GATHER_NONE = 3    /* reported by yahr_multi_transport for a one-device object: no exchange */
+};
+typedef struct yahr_multi yahr_multi;
+/* devices: n_devices indices, or NULL for 0..n_devices-1 (the first is the root).  gather: YAHR_GATHER_AUTO/RCCL/PEER;
+ * naming a transport explicitly runs it even with one device (self send / self copy).  strip_rows <= 0: 8. */
+int yahr_multi_create(const yahr_scene *scene, int n_devices, const int *devices, int gather, int32_t strip_rows,
+                      yahr_multi **out);
+/* renders one frame (opts: spp, seed, traverse, collect_stats; sharding fields are set by the object) into the
+ * HOST buffer rgb_out (height*width*3 floats); synchronous.  Repeated calls reuse contexts, buffers and communicators. */
+int yahr_multi_render(yahr_multi *m, const yahr_render_opts *opts, float *rgb_out, yahr_stats *stats_or_null);
+int yahr_multi_transport(const yahr_multi *m);           /* YAHR_GATHER_RCCL / _PEER / _NONE actually in use */
+double yahr_multi_last_gather_ms(const yahr_multi *m);   /* device time of the last frame's exchange + placement */
+void yahr_multi_destroy(yahr_multi *m);
+/* one-shot: create + render + destroy */
 int yahr_render_multi(const yahr_scene *scene, int n_devices, const yahr_render_opts *opts,
                       float *rgb_out, yahr_stats *stats_or_null);
 

@@ -760,3 +760,35 @@ def test_error_paths_do_not_leak_device_memory(gpu):
         assert abs(free_now() - free0) <= slack
     finally:
         L.yahr_debug_fail_alloc(0)
+
+
+def test_multi_object_both_transports_on_one_device(gpu):
+    """yahr_multi (the single-process multi-GPU form behind the C ABI) on the one GPU of the test box: AUTO with one
+    device does no exchange; naming a transport runs it anyway -- a one-rank RCCL communicator with a self
+    send/recv (librccl loaded lazily), and the strided peer copy onto the same device -- and each must give the
+    unsharded image bit for bit, repeatedly (contexts, buffers and communicators are reused), with exact counters."""
+    d = scenes.pseudo_bunny(203, 117, n_lon=48, n_lat=25)
+    scene = d.to_scene().build()
+    full, st0 = yahr_amd.render_image(scene, collect_stats=True)
+    for gather, want in ((yahr_amd.GATHER_AUTO, yahr_amd.GATHER_NONE), (yahr_amd.GATHER_PEER, yahr_amd.GATHER_PEER),
+                         (yahr_amd.GATHER_RCCL, yahr_amd.GATHER_RCCL)):
+        for strip in (8, 5):
+            m = yahr_amd.MultiContext(scene, 1, gather=gather, strip_rows=strip)
+            assert m.transport == want
+            for _ in range(3):
+                img, st = m.render(collect_stats=True)
+                assert np.array_equal(bits(img), bits(full)), (gather, strip)
+                for k in COUNT_KEYS:
+                    assert st[k] == st0[k], k
+            img4, _ = m.render(spp=4, seed=3)
+            ref4, _ = yahr_amd.render_image(scene, spp=4, seed=3)
+            assert np.array_equal(bits(img4), bits(ref4))
+            if want != yahr_amd.GATHER_NONE:
+                assert m.last_gather_ms > 0
+            m.close()
+    one, _ = yahr_amd.render_image(scene, n_devices=1)                     # the one-shot form the CLI uses
+    assert np.array_equal(bits(one), bits(full))
+    with pytest.raises(yahr_amd.YahrError):
+        yahr_amd.MultiContext(scene, yahr_amd.device_count() + 1)
+    with pytest.raises(yahr_amd.YahrError):
+        yahr_amd.MultiContext(scene, 2, devices=[0, 0])

@@ -93,6 +93,9 @@ def test_device_entry_points_fail_loudly_without_a_gpu():
     assert e.value.code == -6
     with pytest.raises(yahr_amd.YahrError):
         yahr_amd.render_image(s, n_devices=2)
+    with pytest.raises(yahr_amd.YahrError) as e:
+        yahr_amd.MultiContext(s, 2)
+    assert e.value.code == -6
 
 
 def test_malformed_flat_scene_is_rejected_before_any_launch():

@@ -9,6 +9,7 @@ export TMPDIR=/tmp; cd /tmp
 CMD="python3 /root/repo/bench.py $ARGS --no-cpu-baseline --repeats 2"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1 || echo FAIL trace
 find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
+python3 /root/repo/tools/trace_stats.py $OUT/trace > $OUT/kernel_stats_by_grid.csv
 grep '^{"metric"' $OUT/trace.log | tail -1 > $OUT/bench_line_under_rocprof.json
 for pass in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU" \
             "SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_BRANCH SQ_THREAD_CYCLES_VALU" \
@@ -18,4 +19,4 @@ for pass in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY
 done
 python3 /root/repo/tools/pmc_summary.py $OUT/pmc > $OUT/pmc_summary.txt
 rm -rf $OUT/pmc $OUT/trace                     # keep the summaries, not the raw per-dispatch CSVs / databases
-cat $OUT/pmc_summary.txt; head -4 $OUT/kernel_stats.csv
+cat $OUT/pmc_summary.txt; head -5 $OUT/kernel_stats_by_grid.csv

@@ -17,11 +17,11 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import (SPLIT_MIDPOINT, SPLIT_SAH, TILES_REFERENCE, TILES_WAVE, TRAVERSE_AUTO, TRAVERSE_HYBRID,
+from ._lib import (GATHER_AUTO, GATHER_NONE, GATHER_PEER, GATHER_RCCL, SPLIT_MIDPOINT, SPLIT_SAH, TILES_REFERENCE, TILES_WAVE, TRAVERSE_AUTO, TRAVERSE_HYBRID,
                    TRAVERSE_LANE, TRAVERSE_PACKET, TUNE_CENTRE_FIRST, TUNE_ONE_PIXEL_PER_LANE, TUNE_REGROUP, TUNE_XCD_BANDS, RenderOpts, Stats,
                    YahrError, check, lib)
 
-__all__ = ["Scene", "Context", "render_image", "square_batches", "batch_window", "n_batches", "shard_rows",
+__all__ = ["Scene", "Context", "MultiContext", "GATHER_AUTO", "GATHER_RCCL", "GATHER_PEER", "GATHER_NONE", "device_mem_info", "render_image", "square_batches", "batch_window", "n_batches", "shard_rows",
            "shard_global_rows", "write_png", "write_ppm", "write_pfm", "device_count", "YahrError",
            "SPLIT_MIDPOINT", "SPLIT_SAH", "TRAVERSE_AUTO", "TRAVERSE_LANE", "TRAVERSE_PACKET", "TRAVERSE_HYBRID",
            "TILES_WAVE", "TILES_REFERENCE", "TUNE_XCD_BANDS", "TUNE_CENTRE_FIRST", "TUNE_REGROUP", "TUNE_ONE_PIXEL_PER_LANE"]
@@ -299,6 +299,41 @@ class Context:
         rays = np.zeros((uv.shape[0], 7), dtype=np.float32)
         check(lib.yahr_ctx_camera_rays(self._h, uv.shape[0], _fptr(uv), _fptr(rays)))
         return rays
+
+
+class MultiContext:
+    """All GPUs of the node from one process (yahr_multi): resident scenes, one RCCL / peer-DMA gather per frame."""
+
+    def __init__(self, scene, n_devices=1, devices=None, gather=GATHER_AUTO, strip_rows=8):
+        self.scene = scene
+        h = C.c_void_p()
+        devs = None if devices is None else (C.c_int * len(devices))(*devices)
+        check(lib.yahr_multi_create(scene.flat, n_devices, devs, gather, strip_rows, C.byref(h)))
+        self._h = h
+
+    @property
+    def transport(self):
+        return int(lib.yahr_multi_transport(self._h))
+
+    @property
+    def last_gather_ms(self):
+        return float(lib.yahr_multi_last_gather_ms(self._h))
+
+    def render(self, **kw):
+        """one frame -> (numpy [h, w, 3], stats dict)"""
+        o = make_opts(**kw)
+        out = np.zeros((self.scene.height, self.scene.width, 3), dtype=np.float32)
+        st = Stats()
+        check(lib.yahr_multi_render(self._h, C.byref(o), _fptr(out), C.byref(st)))
+        return out, st.as_dict()
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and lib is not None:
+            lib.yahr_multi_destroy(h)
+
+    def __del__(self):
+        self.close()
 
 
 def render_image(scene, device=0, n_devices=1, **kw):

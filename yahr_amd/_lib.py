@@ -13,6 +13,7 @@ ERR_NAMES = {-1: "YAHR_E_ARG", -2: "YAHR_E_PARSE", -3: "YAHR_E_IO", -4: "YAHR_E_
 SPLIT_MIDPOINT, SPLIT_SAH = 0, 1
 TRAVERSE_AUTO, TRAVERSE_LANE, TRAVERSE_PACKET, TRAVERSE_HYBRID = 0, 1, 2, 3
 TILES_WAVE, TILES_REFERENCE = 0, 1
+GATHER_AUTO, GATHER_RCCL, GATHER_PEER, GATHER_NONE = 0, 1, 2, 3
 TUNE_XCD_BANDS, TUNE_CENTRE_FIRST, TUNE_REGROUP, TUNE_ONE_PIXEL_PER_LANE = 1, 2, 4, 8      # yahr_render_opts.tuning bits (diagnostics)
 
 
@@ -113,6 +114,11 @@ SIGNATURES = {
     "yahr_ctx_camera_rays": (C.c_int, [_VP, C.c_int32, _F3, _F3]),
     "yahr_render_rows": (C.c_int, [C.POINTER(FlatScene), C.c_int32, C.c_int32, C.c_int, C.POINTER(RenderOpts), _F3, C.POINTER(Stats)]),
     "yahr_render_multi": (C.c_int, [C.POINTER(FlatScene), C.c_int, C.POINTER(RenderOpts), _F3, C.POINTER(Stats)]),
+    "yahr_multi_create": (C.c_int, [C.POINTER(FlatScene), C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int32, C.POINTER(_VP)]),
+    "yahr_multi_render": (C.c_int, [_VP, C.POINTER(RenderOpts), _F3, C.POINTER(Stats)]),
+    "yahr_multi_transport": (C.c_int, [_VP]),
+    "yahr_multi_last_gather_ms": (C.c_double, [_VP]),
+    "yahr_multi_destroy": (None, [_VP]),
     "yahr_write_png": (C.c_int, [C.c_char_p, _F3, C.c_int32, C.c_int32]),
     "yahr_write_ppm": (C.c_int, [C.c_char_p, _F3, C.c_int32, C.c_int32]),
     "yahr_write_pfm": (C.c_int, [C.c_char_p, _F3, C.c_int32, C.c_int32]),

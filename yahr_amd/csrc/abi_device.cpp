@@ -9,7 +9,6 @@
 #include <cmath>
 #include <cstring>
 #include <string>
-#include <thread>
 #include <vector>
 
 #include "host_scene.hpp"
@@ -502,48 +501,6 @@ int yahr_render_rows(const yahr_scene *scene, int32_t row0, int32_t row1, int de
   if (rc) return fail(rc);
   if (bytes && hipMemcpy(rgb_out, d_rgb, bytes, hipMemcpyDeviceToHost) != hipSuccess) { set_error("hipMemcpy(image) failed"); return fail(YAHR_E_HIP); }
   return fail(YAHR_OK);
-}
-
-int yahr_render_multi(const yahr_scene *scene, int n_devices, const yahr_render_opts *opts, float *rgb_out, yahr_stats *stats) {
-  if (!scene || !rgb_out || n_devices < 1) { set_error("bad arguments"); return YAHR_E_ARG; }
-  int have = yahr_device_count();
-  if (have < 1) { set_error("no HIP device available (libyahr_hip has no CPU fallback)"); return YAHR_E_NODEVICE; }
-  if (n_devices > have) { set_error("more devices requested than visible"); return YAHR_E_NODEVICE; }
-  yahr_render_opts base; if (opts) base = *opts; else yahr_default_opts(&base);
-  const int strip = base.strip_rows > 0 ? base.strip_rows : 8;
-  std::vector<int> rcs((size_t)n_devices, 0);
-  std::vector<std::string> errs((size_t)n_devices);
-  std::vector<yahr_stats> sts((size_t)n_devices);
-  std::vector<std::vector<float>> bufs((size_t)n_devices);
-  std::vector<std::thread> th;
-  for (int d = 0; d < n_devices; ++d) {
-    th.emplace_back([&, d] {
-      yahr_render_opts o = base; o.n_shards = n_devices; o.shard = d; o.strip_rows = strip;
-      if (n_devices == 1) { o.n_shards = 1; }
-      int32_t rows = yahr_shard_rows(scene->height, n_devices, d, strip);
-      bufs[(size_t)d].assign((size_t)rows * scene->width * 3, 0.0f);
-      rcs[(size_t)d] = yahr_render_rows(scene, 0, scene->height, d, &o, bufs[(size_t)d].data(), &sts[(size_t)d]);
-      if (rcs[(size_t)d]) errs[(size_t)d] = yahr_last_error();
-    });
-  }
-  for (auto &t : th) t.join();
-  yahr_stats total; std::memset(&total, 0, sizeof total);
-  for (int d = 0; d < n_devices; ++d) {
-    if (rcs[(size_t)d]) { set_error("device " + std::to_string(d) + ": " + errs[(size_t)d]); return rcs[(size_t)d]; }
-    int32_t rows = yahr_shard_rows(scene->height, n_devices, d, strip);
-    for (int32_t lv = 0; lv < rows; ++lv) {
-      int32_t gv = yahr_shard_global_row(lv, n_devices, d, strip);
-      std::memcpy(rgb_out + (size_t)gv * scene->width * 3, bufs[(size_t)d].data() + (size_t)lv * scene->width * 3, sizeof(float) * 3 * (size_t)scene->width);
-    }
-    const yahr_stats &s = sts[(size_t)d];
-    total.primary_rays += s.primary_rays; total.reflection_rays += s.reflection_rays; total.shadow_rays += s.shadow_rays;
-    total.box_tests += s.box_tests; total.tri_tests += s.tri_tests; total.sphere_tests += s.sphere_tests;
-    total.shaded_hits += s.shaded_hits; total.wave_node_steps += s.wave_node_steps; total.wave_prim_steps += s.wave_prim_steps;
-    if (s.kernel_ms > total.kernel_ms) total.kernel_ms = s.kernel_ms;
-    if (s.upload_ms > total.upload_ms) total.upload_ms = s.upload_ms;
-  }
-  if (stats) *stats = total;
-  return YAHR_OK;
 }
 
 }  // extern "C"

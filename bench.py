@@ -146,7 +146,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="bunny", choices=sorted(WORKLOADS))
-    ap.add_argument("--traverse", default="auto", choices=["auto", "lane", "packet", "hybrid"])
+    ap.add_argument("--traverse", default="auto", choices=["auto", "lane", "packet", "hybrid", "stream"])
     ap.add_argument("--strip-rows", type=int, default=8)
     ap.add_argument("--frames-per-launch", type=int, default=8, help="per rank; a launch holds this x ranks frames")
     ap.add_argument("--repeats", type=int, default=0, help="repeats of the K-step block inside the timed region; 0 = "
@@ -182,7 +182,7 @@ def main():
     w, h = scene.width, scene.height
     K = args.steps
     trav = {"auto": yahr_amd.TRAVERSE_AUTO, "lane": yahr_amd.TRAVERSE_LANE, "packet": yahr_amd.TRAVERSE_PACKET,
-            "hybrid": yahr_amd.TRAVERSE_HYBRID}[args.traverse]
+            "hybrid": yahr_amd.TRAVERSE_HYBRID, "stream": yahr_amd.TRAVERSE_STREAM}[args.traverse]
     # frames per launch: 8 per rank (every rank then gets as many tiles per launch as in the 1-GPU case, so the
     # per-launch tail stays amortised and the gathers get larger and fewer), never more than K
     F = max(1, min(args.frames_per_launch * world, K))

@@ -166,7 +166,10 @@ enum {
   YAHR_TRAVERSE_AUTO = 0,      /* chosen per scene at yahr_ctx_create: PACKET for trees with fat leaves, else HYBRID */
   YAHR_TRAVERSE_LANE = 1,      /* every lane walks the node array on its own (vector loads) */
   YAHR_TRAVERSE_PACKET = 2,    /* the wavefront walks the union of its lanes' paths (scalar node loads) */
-  YAHR_TRAVERSE_HYBRID = 3     /* adaptive: a packet while the rays stay coherent, then every lane on its own */
+  YAHR_TRAVERSE_HYBRID = 3,    /* adaptive: a packet while the rays stay coherent, then every lane on its own */
+  YAHR_TRAVERSE_STREAM = 4     /* wavefront form: camera rays as packets, then ONE LAUNCH PER RECURSION LEVEL with the
+                                  surviving paths compacted into a queue in HBM between launches (ballot + prefix),
+                                  so every wavefront of a level starts with 64 live rays; same image, same counters */
 };
 enum {
   YAHR_TILES_WAVE = 0,         /* 8x8-pixel tile per wavefront */

@@ -22,7 +22,9 @@ from yahr_amd import scenes
 pytestmark = pytest.mark.gpu
 
 REL_TOL, ABS_TOL = 1e-4, 1e-6
-MODES = [yahr_amd.TRAVERSE_LANE, yahr_amd.TRAVERSE_PACKET, yahr_amd.TRAVERSE_HYBRID]
+FUSED_MODES = [yahr_amd.TRAVERSE_LANE, yahr_amd.TRAVERSE_PACKET, yahr_amd.TRAVERSE_HYBRID]
+# ... plus the wavefront form (one launch per recursion level, paths compacted in between): same image, same counters
+MODES = FUSED_MODES + [yahr_amd.TRAVERSE_STREAM]
 HERE = os.path.dirname(os.path.abspath(__file__))
 KAT = json.load(open(os.path.join(HERE, "golden", "spec_kat.json")))
 NTHREADS = min(16, os.cpu_count() or 4)
@@ -530,7 +532,7 @@ def test_regrouped_rays_give_the_same_image(gpu):
     for d in (scenes.pseudo_bunny(203, 117, n_lon=48, n_lat=25), scenes.random_tris(3000, 97, 61, bvh_depth=12),
               scenes.scene_fixed(64, 48)):
         scene = d.to_scene().build()
-        for m in MODES:
+        for m in FUSED_MODES:
             ref, st0 = yahr_amd.render_image(scene, traverse=m, collect_stats=True)
             img, st1 = yahr_amd.render_image(scene, traverse=m, collect_stats=True, tuning=yahr_amd.TUNE_REGROUP)
             assert np.array_equal(bits(img), bits(ref)), m

@@ -13,7 +13,7 @@ import yahr_amd
 from yahr_amd import scenes
 
 TR = {"lane": yahr_amd.TRAVERSE_LANE, "packet": yahr_amd.TRAVERSE_PACKET, "hybrid": yahr_amd.TRAVERSE_HYBRID,
-      "auto": yahr_amd.TRAVERSE_AUTO}
+      "auto": yahr_amd.TRAVERSE_AUTO, "stream": yahr_amd.TRAVERSE_STREAM}
 
 def _no_lights(d):
     d.lights = []

@@ -1,14 +1,22 @@
-"""Summarise rocprofv3 --pmc CSVs: mean counter value per dispatch of the timed render kernel, i.e. of the
-k_render<.., false, ..> launches with the largest grid (the F-frame launches of bench.py; single-frame and tail
-launches of the same kernel have smaller grids and are listed separately)."""
-import collections, csv, glob, sys
+"""Summarise rocprofv3 --pmc CSVs: mean counter value per dispatch, per (kernel, grid size).  By default only the
+uncounted render kernels (k_render<.., false, ..> and the k_stream_* kernels of the wavefront form) are listed; of
+k_render only the largest grid (the F-frame launches of bench.py) unless --all-grids.
+usage: pmc_summary.py <dir with one sub-directory per pass> [--all-grids]"""
+import collections, csv, glob, re, sys
 root = sys.argv[1]
-rows = collections.defaultdict(list)          # counter -> [(grid, value)]
+all_grids = "--all-grids" in sys.argv
+rows = collections.defaultdict(list)          # (kernel, counter) -> [(grid, value)]
 for f in sorted(glob.glob(root + "/*/*/*_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        if "k_render" in r["Kernel_Name"] and "false" in r["Kernel_Name"]:
-            rows[r["Counter_Name"]].append((int(r.get("Grid_Size", 0) or 0), float(r["Counter_Value"])))
-for k in sorted(rows):
-    big = max(g for g, _ in rows[k])
-    v = [x for g, x in rows[k] if g == big]
-    print(f"{k:32s} grid={big:10d} n={len(v):4d} mean={sum(v) / len(v):18.1f}")
+        name = r["Kernel_Name"]
+        if not (("k_render" in name or "k_stream" in name) and "true" not in name.split("(")[0]):
+            continue
+        short = re.sub(r"^void ", "", name.split("(")[0])
+        rows[(short, r["Counter_Name"])].append((int(r.get("Grid_Size", 0) or 0), float(r["Counter_Value"])))
+for (k, ctr) in sorted(rows):
+    grids = sorted(set(g for g, _ in rows[(k, ctr)]))
+    if not all_grids:
+        grids = grids[-1:]
+    for g in grids:
+        v = [x for gg, x in rows[(k, ctr)] if gg == g]
+        print(f"{k:34s} {ctr:30s} grid={g:10d} n={len(v):4d} mean={sum(v) / len(v):18.1f}")

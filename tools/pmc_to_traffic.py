@@ -6,10 +6,8 @@ import json, sys
 vals = {}
 for line in open(sys.argv[1]):
     p = line.split()
-    if len(p) >= 4 and p[-1].startswith("mean="):
-        vals[p[0]] = float(p[-1][5:])
-    elif len(p) >= 4 and "mean=" in line:
-        vals[p[0]] = float(line.split("mean=")[1])
+    if "mean=" in line and p[0].startswith("k_render"):         # rows: kernel counter grid=.. n=.. mean=..
+        vals[p[1]] = float(line.split("mean=")[1])
 workload, F, source = sys.argv[2], int(sys.argv[3]), sys.argv[4]
 fetch_kb, write_kb = vals["FETCH_SIZE"], vals["WRITE_SIZE"]
 out = {

@@ -6,7 +6,9 @@ agg = collections.defaultdict(list)
 for f in glob.glob(sys.argv[1] + "/**/*_kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"].split("(")[0].replace("void ", "")
-        agg[(name, int(r["Grid_Size"]), int(r["Workgroup_Size"]), r.get("VGPR_Count", ""), r.get("SGPR_Count", ""),
+        grid = r.get("Grid_Size") or str(int(r.get("Grid_Size_X", 0) or 0) * int(r.get("Grid_Size_Y", 1) or 1) * int(r.get("Grid_Size_Z", 1) or 1))
+        wg = r.get("Workgroup_Size") or str(int(r.get("Workgroup_Size_X", 0) or 0) * int(r.get("Workgroup_Size_Y", 1) or 1) * int(r.get("Workgroup_Size_Z", 1) or 1))
+        agg[(name, int(grid), int(wg), r.get("VGPR_Count", ""), r.get("SGPR_Count", ""),
              r.get("Scratch_Size", r.get("Private_Segment_Size", "")))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 w = csv.writer(sys.stdout)
 w.writerow(["kernel", "grid_threads", "workgroup", "vgpr", "sgpr", "scratch", "calls", "avg_ns", "min_ns", "max_ns", "total_ns"])

@@ -17,13 +17,13 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import (GATHER_AUTO, GATHER_NONE, GATHER_PEER, GATHER_RCCL, SPLIT_MIDPOINT, SPLIT_SAH, TILES_REFERENCE, TILES_WAVE, TRAVERSE_AUTO, TRAVERSE_HYBRID,
+from ._lib import (GATHER_AUTO, GATHER_NONE, GATHER_PEER, GATHER_RCCL, SPLIT_MIDPOINT, SPLIT_SAH, TILES_REFERENCE, TILES_WAVE, TRAVERSE_AUTO, TRAVERSE_HYBRID, TRAVERSE_STREAM,
                    TRAVERSE_LANE, TRAVERSE_PACKET, TUNE_CENTRE_FIRST, TUNE_ONE_PIXEL_PER_LANE, TUNE_REGROUP, TUNE_XCD_BANDS, RenderOpts, Stats,
                    YahrError, check, lib)
 
 __all__ = ["Scene", "Context", "MultiContext", "GATHER_AUTO", "GATHER_RCCL", "GATHER_PEER", "GATHER_NONE", "device_mem_info", "render_image", "square_batches", "batch_window", "n_batches", "shard_rows",
            "shard_global_rows", "write_png", "write_ppm", "write_pfm", "device_count", "YahrError",
-           "SPLIT_MIDPOINT", "SPLIT_SAH", "TRAVERSE_AUTO", "TRAVERSE_LANE", "TRAVERSE_PACKET", "TRAVERSE_HYBRID",
+           "SPLIT_MIDPOINT", "SPLIT_SAH", "TRAVERSE_AUTO", "TRAVERSE_LANE", "TRAVERSE_PACKET", "TRAVERSE_HYBRID", "TRAVERSE_STREAM",
            "TILES_WAVE", "TILES_REFERENCE", "TUNE_XCD_BANDS", "TUNE_CENTRE_FIRST", "TUNE_REGROUP", "TUNE_ONE_PIXEL_PER_LANE"]
 
 

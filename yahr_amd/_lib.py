@@ -11,7 +11,7 @@ ERR_NAMES = {-1: "YAHR_E_ARG", -2: "YAHR_E_PARSE", -3: "YAHR_E_IO", -4: "YAHR_E_
              -6: "YAHR_E_NODEVICE", -7: "YAHR_E_MATERIAL"}
 
 SPLIT_MIDPOINT, SPLIT_SAH = 0, 1
-TRAVERSE_AUTO, TRAVERSE_LANE, TRAVERSE_PACKET, TRAVERSE_HYBRID = 0, 1, 2, 3
+TRAVERSE_AUTO, TRAVERSE_LANE, TRAVERSE_PACKET, TRAVERSE_HYBRID, TRAVERSE_STREAM = 0, 1, 2, 3, 4
 TILES_WAVE, TILES_REFERENCE = 0, 1
 GATHER_AUTO, GATHER_RCCL, GATHER_PEER, GATHER_NONE = 0, 1, 2, 3
 TUNE_XCD_BANDS, TUNE_CENTRE_FIRST, TUNE_REGROUP, TUNE_ONE_PIXEL_PER_LANE = 1, 2, 4, 8      # yahr_render_opts.tuning bits (diagnostics)

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -26,8 +27,12 @@ struct yahr_ctx {
   DCold *d_cams = nullptr; int n_cams = 0;
   int *d_row_order = nullptr; int row_order_n = 0;
   int auto_mode = TRAV_PACKET;
+  int stream_secondary = TRAV_ADAPTIVE;   // walker of the secondary rays in the stream form (YAHR_STREAM_SECONDARY=lane|packet|hybrid)
   unsigned long long *d_ctr = nullptr;
   int4 *d_windows = nullptr; int n_windows = 0, n_chunks = 0, windows_w = 0, windows_h = 0;
+  // wavefront ("stream") form: path queues, per-level results, queue lengths (allocated on first use, grown on demand)
+  void *d_stream = nullptr; size_t stream_bytes = 0;
+  unsigned *d_qcount = nullptr; int qcount_n = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
   double upload_ms = 0;
@@ -132,6 +137,7 @@ int pick_mode(int traverse, int auto_mode = TRAV_PACKET) {
     case YAHR_TRAVERSE_LANE: return TRAV_LANE;
     case YAHR_TRAVERSE_PACKET: return TRAV_PACKET;
     case YAHR_TRAVERSE_HYBRID: return TRAV_ADAPTIVE;
+    case YAHR_TRAVERSE_STREAM: return TRAV_STREAM;
     default: return auto_mode;       // YAHR_TRAVERSE_AUTO: chosen per scene in yahr_ctx_create
   }
 }
@@ -244,6 +250,10 @@ int yahr_ctx_create(const yahr_scene *s, int device, yahr_ctx **out) {
   d.n_nodes = s->n_nodes; d.n_prims = s->n_prims; d.n_mats = s->n_mats; d.n_lights = s->n_lights;
   d.depth = s->depth;
   c->auto_mode = auto_mode_for(s);
+  if (const char *e = std::getenv("YAHR_STREAM_SECONDARY")) {              // diagnostics
+    if (!std::strcmp(e, "lane")) c->stream_secondary = TRAV_LANE;
+    else if (!std::strcmp(e, "packet")) c->stream_secondary = TRAV_PACKET;
+  }
   d.boxes_finite = 1;
   for (int32_t i = 0; i < s->n_nodes && d.boxes_finite; ++i)
     for (int k = 0; k < 3; ++k)
@@ -258,7 +268,7 @@ void yahr_ctx_destroy(yahr_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipFree(c->d_nodes); (void)hipFree(c->d_prims); (void)hipFree(c->d_normals); (void)hipFree(c->d_mats);
   (void)hipFree(c->d_lights); (void)hipFree(c->d_ctr); (void)hipFree(c->d_windows); (void)hipFree(c->d_cold);
-  (void)hipFree(c->d_cams); (void)hipFree(c->d_row_order);
+  (void)hipFree(c->d_cams); (void)hipFree(c->d_row_order); (void)hipFree(c->d_stream); (void)hipFree(c->d_qcount);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   delete c;
@@ -296,6 +306,47 @@ static int ensure_windows(yahr_ctx *c, int n_batches) {
   HIP_TRY(dev_alloc((void **)&c->d_windows, sizeof(int4) * (win.size() + 2)));
   if (!win.empty()) HIP_TRY(hipMemcpy(c->d_windows, win.data(), sizeof(int4) * win.size(), hipMemcpyHostToDevice));
   c->n_windows = n_batches; c->n_chunks = (int)(win.size() / 2); c->windows_w = c->width; c->windows_h = c->height;
+  return YAHR_OK;
+}
+
+// ---- wavefront ("stream") form ------------------------------------------------------------------------
+// bytes per sample of a pass: two ping-pong path queues of 64 B, (w_k, D_k) of every level, the level count
+static size_t stream_bytes_per_sample(int depth) { return 2 * 64 + (size_t)depth * 32 + 1; }
+
+// Can a pass of n_samples be laid out in this device's memory?  (AUTO falls back to the fused kernel if not.)
+static bool stream_fits(yahr_ctx *c, size_t n_samples, int depth) {
+  const size_t need = n_samples * stream_bytes_per_sample(depth) + 4096;
+  if (n_samples == 0 || n_samples > 0x7fffffffULL) return false;
+  if (need <= c->stream_bytes) return true;
+  size_t fr = 0, tot = 0;
+  if (hipMemGetInfo(&fr, &tot) != hipSuccess) return false;
+  return need <= (fr + c->stream_bytes) / 10 * 6;                          // leave 40 % of what is free to the caller
+}
+
+// like ensure_windows: allocates on the first use of a configuration (warm it up once before a graph capture)
+static int ensure_stream(yahr_ctx *c, size_t n_samples, int depth, SParams &sp) {
+  const size_t need = n_samples * stream_bytes_per_sample(depth) + 4096;
+  if (need > c->stream_bytes) {
+    if (c->d_stream) { HIP_TRY(hipFree(c->d_stream)); c->d_stream = nullptr; c->stream_bytes = 0; }
+    HIP_TRY(dev_alloc(&c->d_stream, need));
+    c->stream_bytes = need;
+  }
+  if (depth + 1 > c->qcount_n) {
+    if (c->d_qcount) { HIP_TRY(hipFree(c->d_qcount)); c->d_qcount = nullptr; c->qcount_n = 0; }
+    HIP_TRY(dev_alloc((void **)&c->d_qcount, sizeof(unsigned) * (size_t)(depth + 1)));
+    c->qcount_n = depth + 1;
+  }
+  char *p = (char *)c->d_stream;
+  for (int s = 0; s < 2; ++s) {
+    sp.qa[s] = (float4 *)p; p += 16 * n_samples;
+    sp.qb[s] = (float4 *)p; p += 16 * n_samples;
+    sp.qc[s] = (float4 *)p; p += 16 * n_samples;
+    sp.qd[s] = (float4 *)p; p += 16 * n_samples;
+  }
+  sp.lev = (float4 *)p; p += 32 * (size_t)depth * n_samples;
+  sp.levels = (unsigned char *)p;
+  sp.count = c->d_qcount;
+  sp.capacity = (unsigned)n_samples;
   return YAHR_OK;
 }
 
@@ -369,8 +420,43 @@ int yahr_ctx_render(yahr_ctx *c, int32_t row0, int32_t row1, const yahr_render_o
     if ((int64_t)n_blocks * rp.frames > 0x7fffffffLL) { set_error("frame batch too large for one grid"); return YAHR_E_ARG; }
     n_blocks *= rp.frames;
   }
+  int mode = pick_mode(o.traverse, c->auto_mode);
+  if (mode == TRAV_STREAM) {
+    // one pass per frame of the batch: camera-ray launch, one launch per recursion level, resolve
+    const size_t n_samples = (size_t)rp.n_local_rows * (size_t)c->width * (size_t)o.spp;
+    const bool can = rp.tile_mode == 0 && !regroup && rp.row_order == nullptr && !rp.xcd_swizzle && stream_fits(c, n_samples, c->ds.depth);
+    if (!can) {
+      if (o.traverse == YAHR_TRAVERSE_STREAM) {
+        set_error("stream traversal needs wave tiles, no tuning bits and " +
+                  std::to_string(n_samples * stream_bytes_per_sample(c->ds.depth) >> 20) + " MiB of free device memory");
+        return YAHR_E_ARG;
+      }
+      mode = TRAV_ADAPTIVE;                                                // AUTO: the fused kernel
+    }
+  }
   HIP_TRY(hipEventRecord(c->ev0, st));
-  HIP_TRY(yahr_dev::launch_render(c->ds, rp, pick_mode(o.traverse, c->auto_mode), regroup, n_blocks, d_rgb, c->d_ctr, o.collect_stats != 0, st));
+  if (mode == TRAV_STREAM) {
+    const size_t n_samples = (size_t)rp.n_local_rows * (size_t)c->width * (size_t)o.spp;
+    const int frames = rp.frames, tiles = n_blocks / frames;
+    const size_t stride = rp.frame_stride;
+    const DCold *cams = rp.cams;
+    SParams sp{};
+    if (c->ds.depth <= 0) {                                                // vcast 0 _ = 0: no ray is cast at all
+      for (int f = 0; f < frames; ++f)
+        HIP_TRY(hipMemsetAsync(d_rgb + (size_t)f * stride, 0, sizeof(float) * 3 * (size_t)rp.n_local_rows * (size_t)c->width, st));
+    } else {
+      int rc = ensure_stream(c, n_samples, c->ds.depth, sp); if (rc) return rc;
+      rp.frames = 1; rp.cams = nullptr; rp.frame_stride = 0;
+      for (int f = 0; f < frames; ++f) {
+        sp.cam = cams ? cams + f : c->ds.cold;
+        HIP_TRY(hipMemsetAsync(c->d_qcount, 0, sizeof(unsigned) * (size_t)(c->ds.depth + 1), st));
+        HIP_TRY(yahr_dev::launch_stream_pass(c->ds, rp, sp, c->stream_secondary, tiles, d_rgb + (size_t)f * stride, c->d_ctr,
+                                             o.collect_stats != 0, st));
+      }
+    }
+  } else {
+    HIP_TRY(yahr_dev::launch_render(c->ds, rp, mode, regroup, n_blocks, d_rgb, c->d_ctr, o.collect_stats != 0, st));
+  }
   HIP_TRY(hipEventRecord(c->ev1, st));
   c->timed = true;
   return YAHR_OK;
@@ -434,6 +520,7 @@ static int ray_query(yahr_ctx *c, int32_t n, const float *rays, int which, int t
   HIP_TRY(d_rays.alloc(sizeof(float) * 7 * (size_t)n));
   HIP_TRY(hipMemcpy(d_rays.p, rays, sizeof(float) * 7 * (size_t)n, hipMemcpyHostToDevice));
   int mode = pick_mode(traverse, c->auto_mode);
+  if (mode == TRAV_STREAM) mode = TRAV_ADAPTIVE;            // single rays: the stream form is a whole-image pipeline
   if (which == 2) {
     HIP_TRY(d_f.alloc(sizeof(float) * 3 * (size_t)n));
     HIP_TRY(yahr_dev::launch_radiance(c->ds, mode, n, d_rays.as<float>(), d_f.as<float>(), c->d_ctr, nullptr));

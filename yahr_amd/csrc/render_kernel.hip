@@ -606,6 +606,24 @@ YD void flush_counters(const Counters &c, unsigned long long *ctr, int lane) {
 
 }  // namespace
 
+// lane -> pixel for the 8x8 wave tiles (tile_mode 0), with samples in lanes and row sharding:
+// lane -> (pixel of the tile, sample of the round): q-th pixel of a (64 >> sil) pixel block, 2^pw wide;
+// local row -> global image row (row sharding, include/yahr_hip.h yahr_render_opts)
+YD void wave_tile_pixel(const RParams &rp, int tile, int lane, int &u, int &gv, size_t &row, bool &valid) {
+  int ty = tile / rp.tiles_x;
+  const int tx = tile - ty * rp.tiles_x;
+  // optional permutation of the tile rows (diagnostics; centre-rows-first measured slower than natural order)
+  if (rp.row_order && tile < rp.n_tiles) ty = rp.row_order[ty];
+  const int q = lane >> rp.sil_log2;
+  const int pw = 1 << rp.pw_log2, ph = (64 >> rp.sil_log2) >> rp.pw_log2;
+  u = tx * pw + (q & (pw - 1));
+  const int lv = ty * ph + (q >> rp.pw_log2);
+  const int strip = lv / rp.strip_rows;
+  gv = rp.row0 + strip * rp.strip_rows * rp.n_shards + (lv - strip * rp.strip_rows);
+  valid = tile < rp.n_tiles && u < rp.width && lv < rp.n_local_rows && gv < rp.height;
+  row = (size_t)lv;
+}
+
 // One wavefront per tile: an 8x8-pixel tile, or one of the reference's squareBatches windows (Sampling.hs:5-21)
 // walked 64 pixels at a time, u-major like the reference.  WPB = 1: one wave per workgroup.  WPB = 4: a
 // workgroup owns 2x2 tiles (or 4 consecutive window chunks) and regroups its rays before every traversal
@@ -644,20 +662,7 @@ void k_render(DScene sc_in, YD_SCENE_PARAMS, RParams rp, float *__restrict__ out
   // silently turns the packet walker's node fetches into per-lane gathers (tests/test_isa.py guards this).
   int u, gv; size_t row; bool valid;
   if (rp.tile_mode == 0) {
-    int ty = tile / rp.tiles_x;
-    const int tx = tile - ty * rp.tiles_x;
-    // optional permutation of the tile rows (diagnostics; centre-rows-first measured slower than natural order)
-    if (rp.row_order && tile < rp.n_tiles) ty = rp.row_order[ty];
-    // lane -> (pixel of the tile, sample of the round): q-th pixel of a (64 >> sil) pixel block, 2^pw wide
-    const int q = lane >> rp.sil_log2;
-    const int pw = 1 << rp.pw_log2, ph = (64 >> rp.sil_log2) >> rp.pw_log2;
-    u = tx * pw + (q & (pw - 1));
-    const int lv = ty * ph + (q >> rp.pw_log2);
-    // local row -> global image row (row sharding, include/yahr_hip.h yahr_render_opts)
-    const int strip = lv / rp.strip_rows;
-    gv = rp.row0 + strip * rp.strip_rows * rp.n_shards + (lv - strip * rp.strip_rows);
-    valid = tile < rp.n_tiles && u < rp.width && lv < rp.n_local_rows && gv < rp.height;
-    row = (size_t)lv;
+    wave_tile_pixel(rp, tile, lane, u, gv, row, valid);
   } else {
     // 64-pixel chunk of a reference window: {x0,y0,x1,y1}, {first pixel of the chunk, ...}; u-major order
     const int tl = tile < rp.n_tiles ? tile : rp.n_tiles - 1;          // n_tiles = number of chunks here
@@ -707,6 +712,149 @@ void k_render(DScene sc_in, YD_SCENE_PARAMS, RParams rp, float *__restrict__ out
       atomicAdd(&ctr[CTR_SUM_WAVE_CYCLES], dt);
     }
   }
+}
+
+// ---- wavefront ("stream") form: render_kernel.hpp SParams ---------------------------------------------
+// append the live paths of this wavefront to queue `level_out`: ballot, one atomic per wavefront, prefix count
+YD void q_append(const SParams &sp, int level_out, bool alive, int sid, V3 rd, V3 x, V3 n, V3 dpdu, int mat) {
+  const unsigned long long m = __ballot(alive);
+  if (m == 0ULL) return;                                               // wave-uniform
+  const int lane = threadIdx.x & 63;
+  const int leader = __ffsll((long long)m) - 1;
+  unsigned base = 0;
+  if (lane == leader) base = atomicAdd(&sp.count[level_out], (unsigned)__popcll(m));
+  base = (unsigned)__shfl((int)base, leader, 64);
+  if (alive) {
+    const unsigned i = base + (unsigned)__popcll(m & ((1ULL << lane) - 1ULL));
+    const int s = level_out & 1;
+    sp.qa[s][i] = make_float4(x.x, x.y, x.z, __int_as_float(sid));
+    sp.qb[s][i] = make_float4(n.x, n.y, n.z, __int_as_float(mat));
+    sp.qc[s][i] = make_float4(dpdu.x, dpdu.y, dpdu.z, rd.x);
+    sp.qd[s][i] = make_float4(rd.y, rd.z, 0.0f, 0.0f);
+  }
+}
+
+// camera rays: one wavefront per wave tile (same lane -> pixel/sample layout as k_render), closest hit with the
+// packet walker (camera rays are coherent), DifferentialGeometry of the hits -> queue 0
+template <bool STATS>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(YAHR_WAVES, 8)))
+void k_stream_primary(DScene sc_in, YD_SCENE_PARAMS, RParams rp, SParams sp, unsigned long long *__restrict__ ctr) {
+  YD_SCENE_BIND
+  const int lane = threadIdx.x & 63;
+  Counters c = {};
+  bool bad_mat = false;
+  int u, gv; size_t row; bool valid;
+  wave_tile_pixel(rp, (int)blockIdx.x, lane, u, gv, row, valid);
+  const int sw = 1 << rp.sil_log2, j0 = lane & (sw - 1);
+  for (int s0 = 0; s0 < rp.spp; s0 += sw) {
+    float du = 0.0f, dv = 0.0f;                        // spp == 1: the integer pixel corner (main.hs:73)
+    if (rp.spp > 1) sample_offset(u, gv, s0 + j0, rp.n_strata, rp.seed, du, dv);
+    V3 ro, rd;
+    camera_ray(sp.cam, (float)u + du, (float)gv + dv, ro, rd);
+    const int sid = (int)((row * (size_t)rp.width + (size_t)u) * (size_t)rp.spp) + s0 + j0;
+    if (STATS) c.primary += lanes(valid);
+    Hit hit;
+    traverse<TRAV_PACKET, STATS>(sc, valid, false, true, ro, rd, 1e6f, hit, c);
+    const bool alive = valid && hit.prim >= 0;
+    if (STATS) c.shaded += lanes(alive);
+    V3 x = vof(0.0f), n = vof(0.0f), dpdu = vof(0.0f);
+    int mat = -1;
+    if (alive) { mat = surface_of(sc, ro, rd, hit, x, n, dpdu); bad_mat = bad_mat | (mat < 0); }
+    if (valid) sp.levels[sid] = 0;
+    q_append(sp, 0, alive, sid, rd, x, n, dpdu, mat);
+  }
+  const unsigned n_bad = lanes(bad_mat);
+  if (n_bad && lane == 0) atomicAdd(&ctr[CTR_BAD_MAT], (unsigned long long)n_bad);
+  if (STATS) flush_counters(c, ctr, lane);
+}
+
+// one recursion level (vhit, Integrators.hs:32-43) for 64 queued paths per wavefront: directIllumination with a
+// shadow probe per light, (w_k, D_k), then the reflection ray's closest hit -> queue k+1
+template <int MODE, bool STATS>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(YAHR_WAVES_LANE, 8)))
+void k_stream_level(DScene sc_in, YD_SCENE_PARAMS, SParams sp, unsigned long long *__restrict__ ctr) {
+  YD_SCENE_BIND
+  const int lane = threadIdx.x & 63;
+  const int k = sp.level, in = k & 1;
+  const unsigned n_in = sp.count[k];
+  if (blockIdx.x * 64u >= n_in) return;                                // wave-uniform: the grid covers the capacity
+  const unsigned e = blockIdx.x * 64u + (unsigned)lane;
+  const bool valid = e < n_in;
+  const unsigned ei = valid ? e : 0u;
+  const float4 qa = sp.qa[in][ei], qb = sp.qb[in][ei], qc = sp.qc[in][ei], qd = sp.qd[in][ei];
+  const V3 x = xyz(qa), n = xyz(qb), dpdu = xyz(qc), rd = v3(qc.w, qd.x, qd.y);
+  const int sid = __float_as_int(qa.w), mat = __float_as_int(qb.w);
+  Counters c = {};
+  bool bad_mat = false;
+  V3 direct = vof(0.0f);
+  const int L = sc.n_lights;
+  for (int l = 0; l < L; ++l) {                                        // directIllumination, Integrators.hs:50-61
+    bool active = false;
+    V3 qo = x, qdir = rd, cv = vof(0.0f); float qt = 1e6f;
+    if (valid) {
+      const float4 *lights = cold_of(sc)->lights;
+      const float4 l0 = lights[2 * (size_t)l], l1 = lights[2 * (size_t)l + 1];
+      const V3 p2l = xyz(l0) - x;                                      // Lights.hs:17-19
+      const V3 ldir = norm(p2l);
+      const V3 intensity = scale(1.0f / lensq(p2l), xyz(l1));
+      const V3 kf = material_at(sc, mat, n, dpdu, ldir, vneg(rd));     // Integrators.hs:58
+      active = lensq(kf) > 0.0f;                                       // && is lazy: probe only if k /= 0
+      if (active) {
+        const V3 p0 = x + scale(0.001f, ldir);                         // reachable, Rays.hs:49-54
+        const V3 dd = xyz(l0) - p0;
+        qo = p0; qdir = norm(dd); qt = len(dd);
+        cv = scale(fabsf(dot(ldir, n)), kf) * intensity;               // Integrators.hs:60
+      }
+    }
+    if (STATS) c.shadow += lanes(active);
+    Hit hit;
+    traverse<MODE, STATS>(sc, active, true, false, qo, qdir, qt, hit, c);
+    if (valid) direct = direct + ((active && hit.prim < 0) ? cv : vof(0.0f));   // sum = foldl (+) 0, light order
+  }
+  const V3 r = rd - scale(2.0f * dot(rd, n), n);                       // reflectionDir, Integrators.hs:46-47
+  const V3 f_r = material_at(sc, mat, n, dpdu, r, vneg(rd));
+  const V3 w = scale(dot(n, r), f_r);
+  if (valid) {
+    sp.lev[(size_t)(2 * k) * sp.capacity + (unsigned)sid] = make_float4(w.x, w.y, w.z, 0.0f);
+    sp.lev[(size_t)(2 * k + 1) * sp.capacity + (unsigned)sid] = make_float4(direct.x, direct.y, direct.z, 0.0f);
+    sp.levels[sid] = (unsigned char)(k + 1);
+  }
+  if (!sp.last) {
+    const V3 ro2 = x + scale(0.001f, r);                               // Integrators.hs:41-43
+    if (STATS) c.reflection += lanes(valid);
+    Hit hit;
+    traverse<MODE, STATS>(sc, valid, false, false, ro2, r, 1e6f, hit, c);
+    const bool alive = valid && hit.prim >= 0;
+    if (STATS) c.shaded += lanes(alive);
+    V3 x2 = vof(0.0f), n2 = vof(0.0f), dpdu2 = vof(0.0f);
+    int mat2 = -1;
+    if (alive) { mat2 = surface_of(sc, ro2, r, hit, x2, n2, dpdu2); bad_mat = bad_mat | (mat2 < 0); }
+    q_append(sp, k + 1, alive, sid, r, x2, n2, dpdu2, mat2);
+  }
+  const unsigned n_bad = lanes(bad_mat);
+  if (n_bad && lane == 0) atomicAdd(&ctr[CTR_BAD_MAT], (unsigned long long)n_bad);
+  if (STATS) flush_counters(c, ctr, lane);
+}
+
+// per pixel: every sample's levels folded back to front (v = w_k * v + D_k: `(n .* r) @* f r * rs + direct`,
+// Integrators.hs:37), the samples added in sample order from 0, times 1/spp -- the fused kernel's arithmetic
+__global__ __launch_bounds__(256) void k_stream_resolve(RParams rp, SParams sp, int depth, float *__restrict__ out) {
+  const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= (size_t)rp.n_local_rows * (size_t)rp.width) return;
+  V3 acc = vof(0.0f);
+  for (int s = 0; s < rp.spp; ++s) {
+    const size_t sid = p * (size_t)rp.spp + (size_t)s;
+    const int nl = sp.levels[sid];
+    V3 v = vof(0.0f);                                                  // vcast 0 _ = 0 / miss = 0
+    for (int k = nl - 1; k >= 0; --k) {
+      const float4 w = sp.lev[(size_t)(2 * k) * sp.capacity + sid], d = sp.lev[(size_t)(2 * k + 1) * sp.capacity + sid];
+      v = (xyz(w) * v) + xyz(d);
+    }
+    acc = (rp.spp > 1) ? acc + v : v;
+  }
+  if (rp.spp > 1) acc = scale(1.0f / (float)rp.spp, acc);
+  float *px = out + p * 3;                                             // samplesToImage: w*v+u (main.hs:100)
+  px[0] = acc.x; px[1] = acc.y; px[2] = acc.z;
 }
 
 // ---- diagnostic kernels: device functions on arbitrary rays (KAT checks on the GPU) -----------------
@@ -781,6 +929,30 @@ hipError_t launch_render(const DScene &sc, const RParams &rp, int mode, bool reg
     case TRAV_PACKET: return launch_render_mode<TRAV_PACKET, 1>(sc, rp, n_blocks, out, ctr, stats, st);
     default: return launch_render_mode<TRAV_ADAPTIVE, 1>(sc, rp, n_blocks, out, ctr, stats, st);
   }
+}
+
+template <int MODE>
+static void launch_stream_levels(const DScene &sc, SParams sp, int n_level_blocks, unsigned long long *ctr, bool stats,
+                                 hipStream_t st) {
+  for (int k = 0; k < sc.depth; ++k) {
+    sp.level = k; sp.last = (k == sc.depth - 1) ? 1 : 0;
+    if (stats) hipLaunchKernelGGL((k_stream_level<MODE, true>), dim3(n_level_blocks), dim3(64), 0, st, sc, sc.nodes, sc.prims, sc.normals, sp, ctr);
+    else hipLaunchKernelGGL((k_stream_level<MODE, false>), dim3(n_level_blocks), dim3(64), 0, st, sc, sc.nodes, sc.prims, sc.normals, sp, ctr);
+  }
+}
+
+hipError_t launch_stream_pass(const DScene &sc, const RParams &rp, SParams sp, int secondary_mode, int n_blocks, float *out,
+                              unsigned long long *ctr, bool stats, hipStream_t st) {
+  if (stats) hipLaunchKernelGGL((k_stream_primary<true>), dim3(n_blocks), dim3(64), 0, st, sc, sc.nodes, sc.prims, sc.normals, rp, sp, ctr);
+  else hipLaunchKernelGGL((k_stream_primary<false>), dim3(n_blocks), dim3(64), 0, st, sc, sc.nodes, sc.prims, sc.normals, rp, sp, ctr);
+  // the level launches cover the queue's capacity; wavefronts beyond the queue's length exit at once
+  const int n_level_blocks = (int)((sp.capacity + 63u) / 64u);
+  if (secondary_mode == TRAV_LANE) launch_stream_levels<TRAV_LANE>(sc, sp, n_level_blocks, ctr, stats, st);
+  else if (secondary_mode == TRAV_PACKET) launch_stream_levels<TRAV_PACKET>(sc, sp, n_level_blocks, ctr, stats, st);
+  else launch_stream_levels<TRAV_ADAPTIVE>(sc, sp, n_level_blocks, ctr, stats, st);
+  const size_t n_px = (size_t)rp.n_local_rows * (size_t)rp.width;
+  hipLaunchKernelGGL(k_stream_resolve, dim3((unsigned)((n_px + 255) / 256)), dim3(256), 0, st, rp, sp, sc.depth, out);
+  return hipGetLastError();
 }
 
 hipError_t launch_trace(const DScene &sc, int mode, int n, const float *rays, int any_hit, int *prim_out,

@@ -49,7 +49,27 @@ struct RParams {
   const int *row_order;    // tile_mode 0: dispatch position -> tile row (centre rows first), or NULL = natural
 };
 
-enum { TRAV_LANE = 1, TRAV_PACKET = 2, TRAV_ADAPTIVE = 3 };
+// Wavefront ("stream") form of the same path, for scenes whose secondary rays are incoherent: the radiance
+// recursion (Integrators.hs:22-43) is cut at its level boundaries into separate launches, and between two launches
+// the surviving paths are COMPACTED (ballot + prefix count + one atomic per wavefront) into a queue in HBM, so that
+// every wavefront of the next launch starts with 64 live rays instead of the ~36 % that hit something.
+//   k_stream_primary   camera rays (packet walker), closest hit, DifferentialGeometry -> queue 0
+//   k_stream_level k   per queued path: shadow probes of every light, (w_k, D_k) -> level arrays, reflection ray,
+//                      closest hit, DifferentialGeometry -> queue k+1            (one launch per recursion level)
+//   k_stream_resolve   per pixel: fold the levels back to front per sample, add the samples in sample order
+// Per ray exactly the fused kernel's arithmetic and tests, so images and counters are bit-identical to it.
+struct SParams {
+  float4 *qa[2], *qb[2], *qc[2], *qd[2];   // path queues (ping-pong by level parity), 64 B per path:
+                                           //   a = {x, sample id}  b = {n, material}  c = {dpdu, rd.x}  d = {rd.y, rd.z, -, -}
+  unsigned *count;                         // [depth + 1] queue lengths
+  float4 *lev;                             // [(2 k + {0: w_k, 1: D_k}) * capacity + sample id]
+  unsigned char *levels;                   // [capacity] number of levels whose ray hit something, per sample
+  unsigned capacity;                       // samples of this pass = local rows x width x spp
+  const DCold *cam;                        // camera of this pass
+  int level, last;                         // k_stream_level: recursion level k, and whether it is the last one
+};
+
+enum { TRAV_LANE = 1, TRAV_PACKET = 2, TRAV_ADAPTIVE = 3, TRAV_STREAM = 4 };
 
 enum { CTR_PRIMARY = 0, CTR_REFLECTION, CTR_SHADOW, CTR_SHADED, CTR_BAD_MAT,
        CTR_BOX, CTR_TRI, CTR_SPH, CTR_WAVE_NODES, CTR_WAVE_PRIMS, CTR_COUNT,
@@ -64,4 +84,7 @@ hipError_t launch_trace(const DScene &sc, int mode, int n, const float *rays, in
 hipError_t launch_radiance(const DScene &sc, int mode, int n, const float *rays, float *rgb,
                            unsigned long long *ctr, hipStream_t st);
 hipError_t launch_camera_rays(const DScene &sc, int n, const float *uv, float *rays, hipStream_t st);
+// stream form: one pass = primary + depth level launches + resolve, all on `st`; sp.count must be zeroed by the caller
+hipError_t launch_stream_pass(const DScene &sc, const RParams &rp, SParams sp, int secondary_mode, int n_blocks, float *out,
+                              unsigned long long *ctr, bool stats, hipStream_t st);
 }  // namespace yahr_dev

@@ -27,7 +27,8 @@ struct yahr_ctx {
   DCold *d_cams = nullptr; int n_cams = 0;
   int *d_row_order = nullptr; int row_order_n = 0;
   int auto_mode = TRAV_PACKET;
-  int stream_passes = 4;                  // passes of a resumable trace in the stream form (YAHR_STREAM_PASSES, diagnostics)
+  int stream_secondary = TRAV_ADAPTIVE;   // walker of the secondary rays in the stream form (measured on 1 M triangles, 16 spp:
+                                          // adaptive 47.9 ms = lane 47.9 ms, packet 77.8 ms)
   unsigned long long *d_ctr = nullptr;
   int4 *d_windows = nullptr; int n_windows = 0, n_chunks = 0, windows_w = 0, windows_h = 0;
   // wavefront ("stream") form: path queues, per-level results, queue lengths (allocated on first use, grown on demand)
@@ -252,10 +253,6 @@ int yahr_ctx_create(const yahr_scene *s, int device, yahr_ctx **out) {
   d.n_nodes = s->n_nodes; d.n_prims = s->n_prims; d.n_mats = s->n_mats; d.n_lights = s->n_lights;
   d.depth = s->depth;
   c->auto_mode = auto_mode_for(s);
-  if (const char *e = std::getenv("YAHR_STREAM_PASSES")) {                 // diagnostics
-    const int v = std::atoi(e);
-    if (v >= 1 && v <= 16) c->stream_passes = v;
-  }
   d.boxes_finite = 1;
   for (int32_t i = 0; i < s->n_nodes && d.boxes_finite; ++i)
     for (int k = 0; k < 3; ++k)
@@ -312,14 +309,12 @@ static int ensure_windows(yahr_ctx *c, int n_batches) {
 }
 
 // ---- wavefront ("stream") form ------------------------------------------------------------------------
-// bytes per sample of a pass: two ping-pong path queues of 64 B, (w_k, D_k) of every level, the level count, the ray
-// queue of a trace (48 B) and its half-size continuation queue, and res / cv / direct per path (16 B each)
-static size_t stream_bytes_per_sample(int depth) { return 2 * 64 + (size_t)depth * 32 + 1 + 48 + 24 + 3 * 16; }
-static const size_t kStreamSlack = 64 * 48 * 2 + 32 * 256 + 4096;
+// bytes per sample of a pass: two ping-pong path queues of 64 B, (w_k, D_k) of every level, the level count
+static size_t stream_bytes_per_sample(int depth) { return 2 * 64 + (size_t)depth * 32 + 1; }
 
 // Can a pass of n_samples be laid out in this device's memory?  (AUTO falls back to the fused kernel if not.)
 static bool stream_fits(yahr_ctx *c, size_t n_samples, int depth) {
-  const size_t need = n_samples * stream_bytes_per_sample(depth) + kStreamSlack;
+  const size_t need = n_samples * stream_bytes_per_sample(depth) + 4096;
   if (n_samples == 0 || n_samples > 0x7fffffffULL) return false;
   if (need <= c->stream_bytes) return true;
   size_t fr = 0, tot = 0;
@@ -328,34 +323,28 @@ static bool stream_fits(yahr_ctx *c, size_t n_samples, int depth) {
 }
 
 // like ensure_windows: allocates on the first use of a configuration (warm it up once before a graph capture)
-static int ensure_stream(yahr_ctx *c, size_t n_samples, int depth, int n_passes, SParams &sp) {
-  const size_t need = n_samples * stream_bytes_per_sample(depth) + kStreamSlack;
+static int ensure_stream(yahr_ctx *c, size_t n_samples, int depth, SParams &sp) {
+  const size_t need = n_samples * stream_bytes_per_sample(depth) + 4096;
   if (need > c->stream_bytes) {
     if (c->d_stream) { HIP_TRY(hipFree(c->d_stream)); c->d_stream = nullptr; c->stream_bytes = 0; }
     HIP_TRY(dev_alloc(&c->d_stream, need));
     c->stream_bytes = need;
   }
-  const int n_count = depth + 1 + n_passes + 1;
-  if (n_count > c->qcount_n) {
+  if (depth + 1 > c->qcount_n) {
     if (c->d_qcount) { HIP_TRY(hipFree(c->d_qcount)); c->d_qcount = nullptr; c->qcount_n = 0; }
-    HIP_TRY(dev_alloc((void **)&c->d_qcount, sizeof(unsigned) * (size_t)n_count));
-    c->qcount_n = n_count;
+    HIP_TRY(dev_alloc((void **)&c->d_qcount, sizeof(unsigned) * (size_t)(depth + 1)));
+    c->qcount_n = depth + 1;
   }
   char *p = (char *)c->d_stream;
-  auto take = [&](size_t bytes) { char *q = p; p += (bytes + 255) & ~(size_t)255; return q; };
-  const size_t half = n_samples / 2 + 64;
   for (int s = 0; s < 2; ++s) {
-    sp.qa[s] = (float4 *)take(16 * n_samples); sp.qb[s] = (float4 *)take(16 * n_samples);
-    sp.qc[s] = (float4 *)take(16 * n_samples); sp.qd[s] = (float4 *)take(16 * n_samples);
-    const size_t nr = s == 0 ? n_samples : half;
-    sp.ca[s] = (float4 *)take(16 * nr); sp.cb[s] = (float4 *)take(16 * nr); sp.cc[s] = (float4 *)take(16 * nr);
+    sp.qa[s] = (float4 *)p; p += 16 * n_samples;
+    sp.qb[s] = (float4 *)p; p += 16 * n_samples;
+    sp.qc[s] = (float4 *)p; p += 16 * n_samples;
+    sp.qd[s] = (float4 *)p; p += 16 * n_samples;
   }
-  sp.res = (float4 *)take(16 * n_samples); sp.cv = (float4 *)take(16 * n_samples); sp.direct = (float4 *)take(16 * n_samples);
-  sp.lev = (float4 *)take(32 * (size_t)depth * n_samples);
-  sp.levels = (unsigned char *)take(n_samples);
-  if ((size_t)(p - (char *)c->d_stream) > c->stream_bytes) { set_error("internal: stream buffer layout exceeds its allocation"); return YAHR_E_HIP; }
+  sp.lev = (float4 *)p; p += 32 * (size_t)depth * n_samples;
+  sp.levels = (unsigned char *)p;
   sp.count = c->d_qcount;
-  sp.rcount = c->d_qcount + depth + 1;
   sp.capacity = (unsigned)n_samples;
   return YAHR_OK;
 }
@@ -455,12 +444,12 @@ int yahr_ctx_render(yahr_ctx *c, int32_t row0, int32_t row1, const yahr_render_o
       for (int f = 0; f < frames; ++f)
         HIP_TRY(hipMemsetAsync(d_rgb + (size_t)f * stride, 0, sizeof(float) * 3 * (size_t)rp.n_local_rows * (size_t)c->width, st));
     } else {
-      int rc = ensure_stream(c, n_samples, c->ds.depth, c->stream_passes, sp); if (rc) return rc;
+      int rc = ensure_stream(c, n_samples, c->ds.depth, sp); if (rc) return rc;
       rp.frames = 1; rp.cams = nullptr; rp.frame_stride = 0;
       for (int f = 0; f < frames; ++f) {
         sp.cam = cams ? cams + f : c->ds.cold;
         HIP_TRY(hipMemsetAsync(c->d_qcount, 0, sizeof(unsigned) * (size_t)(c->ds.depth + 1), st));
-        HIP_TRY(yahr_dev::launch_stream_pass(c->ds, rp, sp, c->stream_passes, tiles, d_rgb + (size_t)f * stride, c->d_ctr,
+        HIP_TRY(yahr_dev::launch_stream_pass(c->ds, rp, sp, c->stream_secondary, tiles, d_rgb + (size_t)f * stride, c->d_ctr,
                                              o.collect_stats != 0, st));
       }
     }

@@ -204,46 +204,6 @@ YD void lane_loop(const DScene &sc, int i, bool any_hit, V3 o, V3 u, V3 inv, flo
   }
 }
 
-
-// The same walk, RESUMABLE: starts at the lane's node index i with its tmax / hit and may stop early.  The skip-linked
-// preorder walk has no stack, so (i, tmax, hit) is a ray's whole traversal state.  Once at least min_steps node steps
-// were taken and at most exit_lanes lanes still have nodes to visit, the parked leaves are scanned and the loop ends;
-// the caller parks the unfinished rays (i < n) for a later pass.  exit_lanes = 0: run to completion.
-template <bool STATS, bool FAST, bool ANY>
-YD void lane_loop_resumable(const DScene &sc, int &i, V3 o, V3 u, V3 inv, float &tmax, Hit &hit, Counters &c,
-                            int exit_lanes, int min_steps) {
-  const int n = sc.n_nodes;
-  int pb = -1, pa = 0, steps = 0;
-  for (;;) {
-    const bool searching = i < n && pb < 0;
-    const unsigned ns = lanes(searching);
-    const bool parked = wany(pb >= 0);
-    if (ns == 0 && !parked) break;
-    const bool leave = steps >= min_steps && (int)lanes(i < n) <= exit_lanes;      // wave-uniform
-    if (leave && !parked) break;
-    if (!leave && (ns >= YD_LEAF_SEARCHERS || !parked)) {       // node step (wave-uniform choice)
-      ++steps;
-      if (searching) {
-        const NodeRec nd = load_node(sc, i);
-        const int a = __float_as_int(nd.lo.w), b = __float_as_int(nd.hi.w);
-        if (STATS) c.box++;
-        const bool h = FAST ? slab_hit_fast(xyz(nd.lo), xyz(nd.hi), o, inv, tmax)
-                            : slab_hit(xyz(nd.lo), xyz(nd.hi), o, inv, tmax);
-        if (h && b >= 0) { pb = b; pa = a; }
-        i = (b >= 0 || h) ? i + 1 : a;
-      }
-    } else if (pb >= 0) {                                       // leaf step
-      for (int k = 0; k < pa; ++k) {
-        const PrimRec p = load_prim(sc, pb + k);
-        if (test_prim_lane<STATS>(sc, pb + k, p, o, u, tmax, hit, c)) {
-          if (ANY) { i = n; break; }
-        }
-      }
-      pb = -1;
-    }
-  }
-}
-
 template <bool STATS>
 YD void traverse_lane(const DScene &sc, bool active, bool any_hit, V3 o, V3 u, float tmax, Hit &hit, Counters &c) {
   const V3 inv = v3(1.0f / u.x, 1.0f / u.y, 1.0f / u.z);
@@ -808,168 +768,79 @@ void k_stream_primary(DScene sc_in, YD_SCENE_PARAMS, RParams rp, SParams sp, uns
   if (STATS) flush_counters(c, ctr, lane);
 }
 
-// ---- per recursion level: small kernels over the path queue of the level, 64 paths per wavefront ---------
-struct PathIn { V3 x, n, dpdu, rd; int sid, mat; bool valid; unsigned e; };
-YD PathIn load_path(const SParams &sp) {
-  PathIn p;
-  const int in = sp.level & 1;
-  const unsigned n_in = sp.count[sp.level];
-  p.e = blockIdx.x * 64u + (threadIdx.x & 63u);
-  p.valid = p.e < n_in;
-  const unsigned ei = p.valid ? p.e : 0u;
-  const float4 qa = sp.qa[in][ei], qb = sp.qb[in][ei], qc = sp.qc[in][ei], qd = sp.qd[in][ei];
-  p.x = xyz(qa); p.n = xyz(qb); p.dpdu = xyz(qc); p.rd = v3(qc.w, qd.x, qd.y);
-  p.sid = __float_as_int(qa.w); p.mat = __float_as_int(qb.w);
-  return p;
-}
-#define YD_STREAM_EXIT_IF_EMPTY(sp) if (blockIdx.x * 64u >= (sp).count[(sp).level]) return;   /* the grid covers the capacity */
-
-// append the rays of the lanes with `cast` set to pass 0 of the trace: node index 0, no hit yet
-YD void ray_emit(const SParams &sp, bool cast, unsigned path, V3 o, V3 u, float tmax) {
-  const unsigned long long m = __ballot(cast);
-  if (m == 0ULL) return;
+// one recursion level (vhit, Integrators.hs:32-43) for 64 queued paths per wavefront: directIllumination with a
+// shadow probe per light, (w_k, D_k), then the reflection ray's closest hit -> queue k+1
+// The grid covers the queue's CAPACITY (its length is known on the device only); wavefronts beyond the length exit at
+// once.  Dispatching those empty 64-thread workgroups costs ~0.8 ms per 518 k of them, but everything tried against it
+// lost more (1 M triangles, 16 spp, ms per frame: one wavefront per workgroup 47.9; four independent wavefronts per
+// workgroup 51.1 -- a workgroup's slots are only released together; a persistent grid of 8192 wavefronts taking chunks
+// in grid-stride order or from an atomic cursor 70+ -- it concentrates the queue-append atomics, and one counter word
+// takes ~90 of them per microsecond).
+#define YD_LEVEL_WAVES 1
+template <int MODE, bool STATS>
+__global__ __launch_bounds__(64 * YD_LEVEL_WAVES) __attribute__((amdgpu_waves_per_eu(YAHR_WAVES_LANE, 8)))
+void k_stream_level(DScene sc_in, YD_SCENE_PARAMS, SParams sp, unsigned long long *__restrict__ ctr) {
+  YD_SCENE_BIND
   const int lane = threadIdx.x & 63;
-  const int leader = __ffsll((long long)m) - 1;
-  unsigned base = 0;
-  if (lane == leader) base = atomicAdd(&sp.rcount[0], (unsigned)__popcll(m));
-  base = (unsigned)__shfl((int)base, leader, 64);
-  if (cast) {
-    const unsigned i = base + (unsigned)__popcll(m & ((1ULL << lane) - 1ULL));
-    sp.ca[0][i] = make_float4(o.x, o.y, o.z, tmax);
-    sp.cb[0][i] = make_float4(u.x, u.y, u.z, __int_as_float((int)path));
-    sp.cc[0][i] = make_float4(__int_as_float(0), __int_as_float(-1), 0.0f, 0.0f);
-  }
-}
-
-// contribution of the light probed before (cv, if it was probed and nothing blocks it) added to the running sum:
-// directIllumination's `sum` = foldl (+) 0 in light order (Integrators.hs:51)
-YD V3 direct_so_far(const SParams &sp, const PathIn &p, int lights_done) {
-  // Branch-free on purpose: all three records are loaded whatever lights_done is and the wave-uniform cases are
-  // selected afterwards.  (Written with `if (lights_done == 1) ... else load direct`, hipcc 7.2 shifted the path index
-  // twice on the lights_done >= 2 path when forming the cv address -- a wild pointer with two lights.)  The arrays
-  // hold `capacity` entries, so reading a record no kernel has written yet is in bounds; its value is never used.
-  const size_t e = p.e;
-  const float4 cv = sp.cv[e], rs = sp.res[e], dd = sp.direct[e];
-  const V3 before = lights_done >= 2 ? xyz(dd) : vof(0.0f);
-  const bool unblocked = (cv.w != 0.0f) & (__float_as_int(rs.x) < 0);
-  const V3 sum = before + (unblocked ? xyz(cv) : vof(0.0f));
-  return lights_done >= 1 ? sum : vof(0.0f);
-}
-
-// Lights.illuminationAtPoint + the BSDF gate of directIllumination for light sp.light (Lights.hs:15-24,
-// Integrators.hs:55-61): cv = |lightDir . n| @* k * intensity is formed before the probe, like in the fused kernel
-template <bool STATS>
-__global__ __launch_bounds__(64) void k_stream_light(DScene sc_in, YD_SCENE_PARAMS, SParams sp, unsigned long long *__restrict__ ctr) {
-  YD_SCENE_BIND
-  YD_STREAM_EXIT_IF_EMPTY(sp)
-  const PathIn p = load_path(sp);
-  const int l = sp.light;
-  bool active = false;
-  V3 qo = p.x, qdir = p.rd, cv = vof(0.0f); float qt = 1e6f;
-  if (p.valid) {
-    if (l > 0) { const V3 d = direct_so_far(sp, p, l); sp.direct[p.e] = make_float4(d.x, d.y, d.z, 0.0f); }
-    const float4 *lights = cold_of(sc)->lights;
-    const float4 l0 = lights[2 * (size_t)l], l1 = lights[2 * (size_t)l + 1];
-    const V3 p2l = xyz(l0) - p.x;                                      // Lights.hs:17-19
-    const V3 ldir = norm(p2l);
-    const V3 intensity = scale(1.0f / lensq(p2l), xyz(l1));
-    const V3 kf = material_at(sc, p.mat, p.n, p.dpdu, ldir, vneg(p.rd));   // Integrators.hs:58
-    active = lensq(kf) > 0.0f;                                         // && is lazy: probe only if k /= 0
-    if (active) {
-      const V3 p0 = p.x + scale(0.001f, ldir);                         // reachable, Rays.hs:49-54
-      const V3 dd = xyz(l0) - p0;
-      qo = p0; qdir = norm(dd); qt = len(dd);
-      cv = scale(fabsf(dot(ldir, p.n)), kf) * intensity;               // Integrators.hs:60
-    }
-    sp.cv[p.e] = make_float4(cv.x, cv.y, cv.z, active ? 1.0f : 0.0f);
-  }
-  ray_emit(sp, active, p.e, qo, qdir, qt);
-  if (STATS) { const unsigned na = lanes(active); if (na && (threadIdx.x & 63) == 0) atomicAdd(&ctr[CTR_SHADOW], (unsigned long long)na); }
-}
-
-// (w_k, D_k) of the level (Integrators.hs:37-40) and the reflection ray (Integrators.hs:41-47)
-template <bool STATS>
-__global__ __launch_bounds__(64) void k_stream_shade(DScene sc_in, YD_SCENE_PARAMS, SParams sp, unsigned long long *__restrict__ ctr) {
-  YD_SCENE_BIND
-  YD_STREAM_EXIT_IF_EMPTY(sp)
-  const PathIn p = load_path(sp);
-  const int k = sp.level;
-  V3 r = vof(0.0f);
-  if (p.valid) {
-    const V3 direct = direct_so_far(sp, p, sp.n_lights);
-    r = p.rd - scale(2.0f * dot(p.rd, p.n), p.n);                      // reflectionDir, Integrators.hs:46-47
-    const V3 f_r = material_at(sc, p.mat, p.n, p.dpdu, r, vneg(p.rd));
-    const V3 w = scale(dot(p.n, r), f_r);
-    sp.lev[(size_t)(2 * k) * sp.capacity + (unsigned)p.sid] = make_float4(w.x, w.y, w.z, 0.0f);
-    sp.lev[(size_t)(2 * k + 1) * sp.capacity + (unsigned)p.sid] = make_float4(direct.x, direct.y, direct.z, 0.0f);
-    sp.levels[p.sid] = (unsigned char)(k + 1);
-  }
-  if (sp.last) return;
-  ray_emit(sp, p.valid, p.e, p.x + scale(0.001f, r), r, 1e6f);
-  if (STATS) { const unsigned na = lanes(p.valid); if (na && (threadIdx.x & 63) == 0) atomicAdd(&ctr[CTR_REFLECTION], (unsigned long long)na); }
-}
-
-// DifferentialGeometry of the reflection rays' hits (Shapes.hs:23-28, 49-55) -> path queue k+1
-template <bool STATS>
-__global__ __launch_bounds__(64) void k_stream_surface(DScene sc_in, YD_SCENE_PARAMS, SParams sp, unsigned long long *__restrict__ ctr) {
-  YD_SCENE_BIND
-  YD_STREAM_EXIT_IF_EMPTY(sp)
-  const PathIn p = load_path(sp);
-  const float4 rs = sp.res[p.valid ? p.e : 0u];
-  Hit hit; hit.prim = __float_as_int(rs.x); hit.t = rs.y; hit.b1 = rs.z; hit.b2 = rs.w;
-  const bool alive = p.valid && hit.prim >= 0;
-  const V3 r = p.rd - scale(2.0f * dot(p.rd, p.n), p.n);               // the ray k_stream_shade cast, bit for bit
-  const V3 ro2 = p.x + scale(0.001f, r);
-  V3 x2 = vof(0.0f), n2 = vof(0.0f), dpdu2 = vof(0.0f);
-  int mat2 = -1;
-  if (alive) mat2 = surface_of(sc, ro2, r, hit, x2, n2, dpdu2);
-  q_append(sp, sp.level + 1, alive, p.sid, r, x2, n2, dpdu2, mat2);
-  const unsigned n_bad = lanes(alive && mat2 < 0);
-  if (n_bad && (threadIdx.x & 63) == 0) atomicAdd(&ctr[CTR_BAD_MAT], (unsigned long long)n_bad);
-  if (STATS) { const unsigned na = lanes(alive); if (na && (threadIdx.x & 63) == 0) atomicAdd(&ctr[CTR_SHADED], (unsigned long long)na); }
-}
-
-// one pass of a trace over the ray queue of parity sp.pass & 1: every lane owns one ray and walks on its own (lane
-// walker: these rays are incoherent).  Finished rays deliver res[path]; the others go to the next pass's queue.
-template <bool ANY, bool STATS>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(YAHR_WAVES_LANE, 8)))
-void k_stream_trace(DScene sc_in, YD_SCENE_PARAMS, SParams sp, unsigned long long *__restrict__ ctr) {
-  YD_SCENE_BIND
-  const int lane = threadIdx.x & 63, in = sp.pass & 1;
-  const unsigned n_in = sp.rcount[sp.pass];
-  if (blockIdx.x * 64u >= n_in) return;                                // wave-uniform
-  const unsigned e = blockIdx.x * 64u + (unsigned)lane;
+  const int k = sp.level, in = k & 1;
+  const unsigned n_in = sp.count[k];
+  const unsigned chunk = blockIdx.x * YD_LEVEL_WAVES + (threadIdx.x >> 6);
+  if (chunk * 64u >= n_in) return;                                     // wave-uniform: the grid covers the capacity
+  const unsigned e = chunk * 64u + (unsigned)lane;
   const bool valid = e < n_in;
   const unsigned ei = valid ? e : 0u;
-  const float4 ra = sp.ca[in][ei], rb = sp.cb[in][ei], rc = sp.cc[in][ei];
-  const V3 o = xyz(ra), u = xyz(rb);
-  float tmax = ra.w;
-  const int path = __float_as_int(rb.w);
-  const int n = sc.n_nodes;
-  int i = valid ? __float_as_int(rc.x) : n;
-  Hit hit; hit.prim = __float_as_int(rc.y); hit.t = tmax; hit.b1 = rc.z; hit.b2 = rc.w;
+  const float4 qa = sp.qa[in][ei], qb = sp.qb[in][ei], qc = sp.qc[in][ei], qd = sp.qd[in][ei];
+  const V3 x = xyz(qa), n = xyz(qb), dpdu = xyz(qc), rd = v3(qc.w, qd.x, qd.y);
+  const int sid = __float_as_int(qa.w), mat = __float_as_int(qb.w);
   Counters c = {};
-  const V3 inv = v3(1.0f / u.x, 1.0f / u.y, 1.0f / u.z);
-  // NaN-free slab form when the whole wave qualifies (see traverse_packet / device_math.hpp)
-  const bool fast = sc.boxes_finite != 0 && !wany(valid & !slab_safe(o, inv));
-  if (fast) lane_loop_resumable<STATS, true, ANY>(sc, i, o, u, inv, tmax, hit, c, sp.exit_lanes, sp.min_steps);
-  else lane_loop_resumable<STATS, false, ANY>(sc, i, o, u, inv, tmax, hit, c, sp.exit_lanes, sp.min_steps);
-  const bool more = valid && i < n;
-  if (valid && !more) sp.res[path] = make_float4(__int_as_float(hit.prim), tmax, hit.b1, hit.b2);
-  const unsigned long long m = __ballot(more);
-  if (m != 0ULL) {                                                     // park the unfinished rays, compacted
-    const int leader = __ffsll((long long)m) - 1;
-    unsigned base = 0;
-    if (lane == leader) base = atomicAdd(&sp.rcount[sp.pass + 1], (unsigned)__popcll(m));
-    base = (unsigned)__shfl((int)base, leader, 64);
-    if (more) {
-      const unsigned j = base + (unsigned)__popcll(m & ((1ULL << lane) - 1ULL));
-      const int out = in ^ 1;
-      sp.ca[out][j] = make_float4(o.x, o.y, o.z, tmax);
-      sp.cb[out][j] = rb;
-      sp.cc[out][j] = make_float4(__int_as_float(i), __int_as_float(hit.prim), hit.b1, hit.b2);
+  bool bad_mat = false;
+  V3 direct = vof(0.0f);
+  const int L = sc.n_lights;
+  for (int l = 0; l < L; ++l) {                                        // directIllumination, Integrators.hs:50-61
+    bool active = false;
+    V3 qo = x, qdir = rd, cv = vof(0.0f); float qt = 1e6f;
+    if (valid) {
+      const float4 *lights = cold_of(sc)->lights;
+      const float4 l0 = lights[2 * (size_t)l], l1 = lights[2 * (size_t)l + 1];
+      const V3 p2l = xyz(l0) - x;                                      // Lights.hs:17-19
+      const V3 ldir = norm(p2l);
+      const V3 intensity = scale(1.0f / lensq(p2l), xyz(l1));
+      const V3 kf = material_at(sc, mat, n, dpdu, ldir, vneg(rd));     // Integrators.hs:58
+      active = lensq(kf) > 0.0f;                                       // && is lazy: probe only if k /= 0
+      if (active) {
+        const V3 p0 = x + scale(0.001f, ldir);                         // reachable, Rays.hs:49-54
+        const V3 dd = xyz(l0) - p0;
+        qo = p0; qdir = norm(dd); qt = len(dd);
+        cv = scale(fabsf(dot(ldir, n)), kf) * intensity;               // Integrators.hs:60
+      }
     }
+    if (STATS) c.shadow += lanes(active);
+    Hit hit;
+    traverse<MODE, STATS>(sc, active, true, false, qo, qdir, qt, hit, c);
+    if (valid) direct = direct + ((active && hit.prim < 0) ? cv : vof(0.0f));   // sum = foldl (+) 0, light order
   }
+  const V3 r = rd - scale(2.0f * dot(rd, n), n);                       // reflectionDir, Integrators.hs:46-47
+  const V3 f_r = material_at(sc, mat, n, dpdu, r, vneg(rd));
+  const V3 w = scale(dot(n, r), f_r);
+  if (valid) {
+    sp.lev[(size_t)(2 * k) * sp.capacity + (unsigned)sid] = make_float4(w.x, w.y, w.z, 0.0f);
+    sp.lev[(size_t)(2 * k + 1) * sp.capacity + (unsigned)sid] = make_float4(direct.x, direct.y, direct.z, 0.0f);
+    sp.levels[sid] = (unsigned char)(k + 1);
+  }
+  if (!sp.last) {
+    const V3 ro2 = x + scale(0.001f, r);                               // Integrators.hs:41-43
+    if (STATS) c.reflection += lanes(valid);
+    Hit hit;
+    traverse<MODE, STATS>(sc, valid, false, false, ro2, r, 1e6f, hit, c);
+    const bool alive = valid && hit.prim >= 0;
+    if (STATS) c.shaded += lanes(alive);
+    V3 x2 = vof(0.0f), n2 = vof(0.0f), dpdu2 = vof(0.0f);
+    int mat2 = -1;
+    if (alive) { mat2 = surface_of(sc, ro2, r, hit, x2, n2, dpdu2); bad_mat = bad_mat | (mat2 < 0); }
+    q_append(sp, k + 1, alive, sid, r, x2, n2, dpdu2, mat2);
+  }
+  const unsigned n_bad = lanes(bad_mat);
+  if (n_bad && lane == 0) atomicAdd(&ctr[CTR_BAD_MAT], (unsigned long long)n_bad);
   if (STATS) flush_counters(c, ctr, lane);
 }
 
@@ -1068,52 +939,28 @@ hipError_t launch_render(const DScene &sc, const RParams &rp, int mode, bool reg
   }
 }
 
-// grid sizes cover the CAPACITY of a queue (its length is known on the device only); wavefronts beyond the length
-// exit at once.  A trace pass leaves at most half of its rays (+ < 64) to the next pass: every wavefront parks at most
-// exit_lanes = 32 of its 64 rays.
-#define YD_LAUNCH(kern, blocks, threads, ...) hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, st, sc, sc.nodes, sc.prims, sc.normals, __VA_ARGS__)
-template <bool STATS>
-static hipError_t stream_pass(const DScene &sc, const RParams &rp, SParams sp, int n_trace_passes, int n_blocks, float *out,
-                              unsigned long long *ctr, hipStream_t st) {
-  YD_LAUNCH((k_stream_primary<STATS>), n_blocks, 64, rp, sp, ctr);
-  const unsigned path_blocks = (sp.capacity + 63u) / 64u;
-  auto trace = [&](bool any_hit) {
-    unsigned cap = sp.capacity;
-    for (int p = 0; p < n_trace_passes; ++p) {
-      sp.pass = p;
-      sp.exit_lanes = (p == n_trace_passes - 1) ? 0 : 32;
-      sp.min_steps = 64;
-      const unsigned blocks = (cap + 63u) / 64u;
-      if (any_hit) YD_LAUNCH((k_stream_trace<true, STATS>), blocks, 64, sp, ctr);
-      else YD_LAUNCH((k_stream_trace<false, STATS>), blocks, 64, sp, ctr);
-      cap = cap / 2u + 64u;
-    }
-  };
-  const size_t rcount_bytes = sizeof(unsigned) * (size_t)(n_trace_passes + 1);
+template <int MODE>
+static void launch_stream_levels(const DScene &sc, SParams sp, int n_level_blocks, unsigned long long *ctr, bool stats,
+                                 hipStream_t st) {
   for (int k = 0; k < sc.depth; ++k) {
-    sp.level = k; sp.last = (k == sc.depth - 1) ? 1 : 0; sp.n_lights = sc.n_lights;
-    for (int l = 0; l < sc.n_lights; ++l) {
-      sp.light = l;
-      (void)hipMemsetAsync(sp.rcount, 0, rcount_bytes, st);
-      YD_LAUNCH((k_stream_light<STATS>), path_blocks, 64, sp, ctr);
-      trace(true);
-    }
-    if (!sp.last) (void)hipMemsetAsync(sp.rcount, 0, rcount_bytes, st);
-    YD_LAUNCH((k_stream_shade<STATS>), path_blocks, 64, sp, ctr);
-    if (!sp.last) {
-      trace(false);
-      YD_LAUNCH((k_stream_surface<STATS>), path_blocks, 64, sp, ctr);
-    }
+    sp.level = k; sp.last = (k == sc.depth - 1) ? 1 : 0;
+    if (stats) hipLaunchKernelGGL((k_stream_level<MODE, true>), dim3(n_level_blocks), dim3(64 * YD_LEVEL_WAVES), 0, st, sc, sc.nodes, sc.prims, sc.normals, sp, ctr);
+    else hipLaunchKernelGGL((k_stream_level<MODE, false>), dim3(n_level_blocks), dim3(64 * YD_LEVEL_WAVES), 0, st, sc, sc.nodes, sc.prims, sc.normals, sp, ctr);
   }
+}
+
+hipError_t launch_stream_pass(const DScene &sc, const RParams &rp, SParams sp, int secondary_mode, int n_blocks, float *out,
+                              unsigned long long *ctr, bool stats, hipStream_t st) {
+  if (stats) hipLaunchKernelGGL((k_stream_primary<true>), dim3(n_blocks), dim3(64), 0, st, sc, sc.nodes, sc.prims, sc.normals, rp, sp, ctr);
+  else hipLaunchKernelGGL((k_stream_primary<false>), dim3(n_blocks), dim3(64), 0, st, sc, sc.nodes, sc.prims, sc.normals, rp, sp, ctr);
+  // the level launches cover the queue's capacity; wavefronts beyond the queue's length exit at once
+  const int n_level_blocks = (int)((sp.capacity + 64u * YD_LEVEL_WAVES - 1u) / (64u * YD_LEVEL_WAVES));
+  if (secondary_mode == TRAV_LANE) launch_stream_levels<TRAV_LANE>(sc, sp, n_level_blocks, ctr, stats, st);
+  else if (secondary_mode == TRAV_PACKET) launch_stream_levels<TRAV_PACKET>(sc, sp, n_level_blocks, ctr, stats, st);
+  else launch_stream_levels<TRAV_ADAPTIVE>(sc, sp, n_level_blocks, ctr, stats, st);
   const size_t n_px = (size_t)rp.n_local_rows * (size_t)rp.width;
   hipLaunchKernelGGL(k_stream_resolve, dim3((unsigned)((n_px + 255) / 256)), dim3(256), 0, st, rp, sp, sc.depth, out);
   return hipGetLastError();
-}
-
-hipError_t launch_stream_pass(const DScene &sc, const RParams &rp, SParams sp, int n_trace_passes, int n_blocks, float *out,
-                              unsigned long long *ctr, bool stats, hipStream_t st) {
-  return stats ? stream_pass<true>(sc, rp, sp, n_trace_passes, n_blocks, out, ctr, st)
-               : stream_pass<false>(sc, rp, sp, n_trace_passes, n_blocks, out, ctr, st);
 }
 
 hipError_t launch_trace(const DScene &sc, int mode, int n, const float *rays, int any_hit, int *prim_out,

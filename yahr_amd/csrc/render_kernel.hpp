@@ -49,43 +49,24 @@ struct RParams {
   const int *row_order;    // tile_mode 0: dispatch position -> tile row (centre rows first), or NULL = natural
 };
 
-// Wavefront ("stream") form of the same path, for scenes whose secondary rays are incoherent.  The radiance
-// recursion (Integrators.hs:22-43) is cut into separate launches at every point where the set of live rays changes,
-// and between two launches the live rays are COMPACTED (ballot + prefix count + one atomic per wavefront) into a
-// queue in HBM, so that wavefronts start with 64 live rays instead of the ~36 % that hit something:
-//   k_stream_primary    camera rays (packet walker), closest hit, DifferentialGeometry -> path queue 0
-//   per recursion level k, for the queued paths:
-//     k_stream_light    Lights.illuminationAtPoint of light l: contribution cv and the shadow ray -> ray queue
-//     k_stream_trace    the shadow rays (first hit)                                          -> res[path]
-//     k_stream_shade    directIllumination sum, (w_k, D_k) -> level arrays, reflection ray   -> ray queue
-//     k_stream_trace    the reflection rays (closest hit)                                    -> res[path]
-//     k_stream_surface  DifferentialGeometry of the hits                                     -> path queue k+1
-//   k_stream_resolve    per pixel: fold the levels back to front per sample, add the samples in sample order
-// k_stream_trace is RESUMABLE: the skip-linked preorder walk has no stack, so a ray's whole traversal state is
-// (node index, tMax, best hit).  A trace runs in a few passes; in every pass but the last a wavefront stops as soon as
-// at most `exit_lanes` of its 64 rays are still walking, parks those rays (with their state) in a continuation queue
-// and the next pass picks them up compacted again -- rays of very different lengths no longer hold a wavefront at
-// ~37 % lane utilisation (1 M triangles), and at most half of a pass's rays reach the next pass.
-// Per ray exactly the fused kernel's arithmetic and tests in the same order, so images and counters are
-// bit-identical to it.
+// Wavefront ("stream") form of the same path, for scenes whose secondary rays are incoherent: the radiance
+// recursion (Integrators.hs:22-43) is cut at its level boundaries into separate launches, and between two launches
+// the surviving paths are COMPACTED (ballot + prefix count + one atomic per wavefront) into a queue in HBM, so that
+// every wavefront of the next launch starts with 64 live rays instead of the ~36 % that hit something.
+//   k_stream_primary   camera rays (packet walker), closest hit, DifferentialGeometry -> queue 0
+//   k_stream_level k   per queued path: shadow probes of every light, (w_k, D_k) -> level arrays, reflection ray,
+//                      closest hit, DifferentialGeometry -> queue k+1            (one launch per recursion level)
+//   k_stream_resolve   per pixel: fold the levels back to front per sample, add the samples in sample order
+// Per ray exactly the fused kernel's arithmetic and tests, so images and counters are bit-identical to it.
 struct SParams {
   float4 *qa[2], *qb[2], *qc[2], *qd[2];   // path queues (ping-pong by level parity), 64 B per path:
                                            //   a = {x, sample id}  b = {n, material}  c = {dpdu, rd.x}  d = {rd.y, rd.z, -, -}
-  unsigned *count;                         // [depth + 1] path queue lengths, then [passes + 1] ray queue lengths
+  unsigned *count;                         // [depth + 1] queue lengths
   float4 *lev;                             // [(2 k + {0: w_k, 1: D_k}) * capacity + sample id]
   unsigned char *levels;                   // [capacity] number of levels whose ray hit something, per sample
   unsigned capacity;                       // samples of this pass = local rows x width x spp
   const DCold *cam;                        // camera of this pass
-  int level, last;                         // recursion level k of the launch, and whether it is the last one
-  // rays of the traversal in flight, 48 B per ray: a = {x0, tMax now}  b = {u, path index}  c = {node index, best
-  // primitive, b1, b2} (the best hit's t IS tMax); ping-pong by pass parity, the second half as large as the first
-  float4 *ca[2], *cb[2], *cc[2];
-  unsigned *rcount;                        // count + depth + 1: [pass] rays entering that pass
-  float4 *res;                             // [path index] {best primitive, t, b1, b2} of the finished traversal
-  float4 *cv;                              // [path index] {cv, active}: contribution of the light being probed
-  float4 *direct;                          // [path index] directIllumination summed over the lights done so far
-  int light, n_lights;                     // k_stream_light: which light
-  int pass, exit_lanes, min_steps;         // k_stream_trace
+  int level, last;                         // k_stream_level: recursion level k, and whether it is the last one
 };
 
 enum { TRAV_LANE = 1, TRAV_PACKET = 2, TRAV_ADAPTIVE = 3, TRAV_STREAM = 4 };
@@ -104,6 +85,6 @@ hipError_t launch_radiance(const DScene &sc, int mode, int n, const float *rays,
                            unsigned long long *ctr, hipStream_t st);
 hipError_t launch_camera_rays(const DScene &sc, int n, const float *uv, float *rays, hipStream_t st);
 // stream form: one pass = primary + depth level launches + resolve, all on `st`; sp.count must be zeroed by the caller
-hipError_t launch_stream_pass(const DScene &sc, const RParams &rp, SParams sp, int n_trace_passes, int n_blocks, float *out,
+hipError_t launch_stream_pass(const DScene &sc, const RParams &rp, SParams sp, int secondary_mode, int n_blocks, float *out,
                               unsigned long long *ctr, bool stats, hipStream_t st);
 }  // namespace yahr_dev

@@ -4,10 +4,11 @@ orbit is what is stored), which bench.py scales by its frames per launch.
 usage: pmc_to_traffic.py <pmc_summary.txt> <workload> <frames per launch> <source text> > profiles/traffic_latest.json"""
 import json, sys
 vals = {}
+import re
 for line in open(sys.argv[1]):
-    p = line.split()
-    if "mean=" in line and p[0].startswith("k_render"):         # rows: kernel counter grid=.. n=.. mean=..
-        vals[p[1]] = float(line.split("mean=")[1])
+    m = re.match(r"^(k_render.*?)\s{2,}(\S+)\s+grid=.*mean=\s*([0-9.eE+-]+)", line)   # rows: kernel  counter  grid=.. n=.. mean=..
+    if m:
+        vals[m.group(2)] = float(m.group(3))
 workload, F, source = sys.argv[2], int(sys.argv[3]), sys.argv[4]
 fetch_kb, write_kb = vals["FETCH_SIZE"], vals["WRITE_SIZE"]
 out = {

@@ -172,7 +172,13 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        # "nccl" is RCCL on ROCm.  YAHR_BENCH_BACKEND=gloo (with YAHR_BENCH_FORCE_DEVICE=0) rehearses the N-rank control
+        # flow on a one-GPU box, where RCCL refuses two ranks on one device; its numbers mean nothing.
+        backend = os.environ.get("YAHR_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     desc, workload_name, target = WORKLOADS[args.workload]()
     t0 = time.perf_counter()

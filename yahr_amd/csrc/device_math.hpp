@@ -70,6 +70,17 @@ YD bool slab_hit_fast(V3 lo, V3 hi, V3 o, V3 inv, float tmax) {
   const float tfar = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax));
   return !(tnear > tfar);
 }
+// The same test as a 64-bit lane mask (v_cmp straight into an SGPR pair / vcc), for the packet walker: the mask is
+// both the wave's "any lane hit" (mask != 0: the vccz branch of the compare itself) and, through inverse_ballot, the
+// lane's own Boolean -- without the v_cndmask 0/1 + v_cmp_ne pair a ballot of a bool costs (2 of 30 VALU per node).
+YD unsigned long long slab_mask_fast(V3 lo, V3 hi, V3 o, V3 inv, float tmax) {
+  const float t0x = (lo.x - o.x) * inv.x, t1x = (hi.x - o.x) * inv.x;
+  const float t0y = (lo.y - o.y) * inv.y, t1y = (hi.y - o.y) * inv.y;
+  const float t0z = (lo.z - o.z) * inv.z, t1z = (hi.z - o.z) * inv.z;
+  const float tnear = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.0f));
+  const float tfar = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax));
+  return __builtin_amdgcn_fcmpf(tnear, tfar, 13);                       // FCMP_ULE: !(tnear > tfar)
+}
 YD bool finite_nonzero(float x) { const float a = fabsf(x); return (a > 0.0f) & (a < __builtin_huge_valf()); }
 YD bool finite_f(float x) { return fabsf(x) < __builtin_huge_valf(); }
 YD bool slab_safe(V3 o, V3 inv) {

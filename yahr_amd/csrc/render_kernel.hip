@@ -262,8 +262,9 @@ YD int wave_min_i32(int v) {
 template <bool FAST>
 YD void packet_box(const NodeRec &nd, bool on, V3 o, V3 inv, float tmax, bool &h, bool &anyh) {
   if (FAST) {
-    h = slab_hit_fast(xyz(nd.lo), xyz(nd.hi), o, inv, on ? tmax : -1.0f);
-    anyh = wany(h);
+    const unsigned long long hm = slab_mask_fast(xyz(nd.lo), xyz(nd.hi), o, inv, on ? tmax : -1.0f);
+    h = __builtin_amdgcn_inverse_ballot_w64(hm);
+    anyh = hm != 0ULL;
   } else {
     const bool hs = slab_hit(xyz(nd.lo), xyz(nd.hi), o, inv, tmax);
     h = hs & on;

@@ -178,9 +178,12 @@ YD void lane_loop(const DScene &sc, int i, bool any_hit, V3 o, V3 u, V3 inv, flo
   // it put a second, dependent gather (the primitive record) into ~85 % of the wave's iterations.
   int pb = -1, pa = 0;
   for (;;) {
-    const bool searching = i < n && pb < 0;
-    const unsigned ns = lanes(searching);
-    const bool parked = wany(pb >= 0);
+    // lane masks straight from the compares (v_cmp into SGPR pairs; a ballot of a bool costs two more VALU)
+    const unsigned long long m_parked = __builtin_amdgcn_sicmp(pb, 0, 39);                       // pb >= 0
+    const unsigned long long m_search = __builtin_amdgcn_sicmp(i, n, 40) & ~m_parked;            // i < n && pb < 0
+    const bool searching = __builtin_amdgcn_inverse_ballot_w64(m_search);
+    const int ns = __builtin_popcountll(m_search);
+    const bool parked = m_parked != 0ULL;
     if (ns == 0 && !parked) break;
     if (ns >= YD_LEAF_SEARCHERS || !parked) {                   // node step (wave-uniform choice)
       if (searching) {

@@ -215,6 +215,8 @@ typedef struct yahr_stats {
   double kernel_ms;                                      /* device time of the render launch(es), HIP events */
   double upload_ms;                                      /* one-shot calls: host->device scene copy */
   uint64_t max_wave_cycles, sum_wave_cycles;             /* shader clocks of the longest wavefront / of all (collect_stats only) */
+  uint64_t wave_stage1_steps, wave_stage2_steps;         /* packet walker: primitive steps that ran the triangle's IEEE divide
+                                                            (not rejected division-free by every live lane) / its second half */
 } yahr_stats;
 
 void yahr_default_opts(yahr_render_opts *o);

@@ -6,7 +6,7 @@ import collections, csv, glob, re, sys
 root = sys.argv[1]
 all_grids = "--all-grids" in sys.argv
 rows = collections.defaultdict(list)          # (kernel, counter) -> [(grid, value)]
-for f in sorted(glob.glob(root + "/*/*/*_counter_collection.csv")):
+for f in sorted(glob.glob(root + "/**/*_counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"]
         if not (("k_render" in name or "k_stream" in name) and "true" not in name.split("(")[0]):

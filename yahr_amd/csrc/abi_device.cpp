@@ -501,6 +501,7 @@ int yahr_ctx_stats(yahr_ctx *c, yahr_stats *out) {
   out->shaded_hits = h[CTR_SHADED]; out->bad_material = h[CTR_BAD_MAT];
   out->box_tests = h[CTR_BOX]; out->tri_tests = h[CTR_TRI]; out->sphere_tests = h[CTR_SPH];
   out->wave_node_steps = h[CTR_WAVE_NODES]; out->wave_prim_steps = h[CTR_WAVE_PRIMS];
+  out->wave_stage1_steps = h[CTR_WAVE_STAGE1]; out->wave_stage2_steps = h[CTR_WAVE_STAGE2];
   out->max_wave_cycles = h[CTR_MAX_WAVE_CYCLES]; out->sum_wave_cycles = h[CTR_SUM_WAVE_CYCLES];
   if (c->timed) { float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1)); out->kernel_ms = ms; }
   out->upload_ms = c->upload_ms;

@@ -273,6 +273,7 @@ int yahr_multi_render(yahr_multi *m, const yahr_render_opts *opts, float *rgb_ou
     total.primary_rays += s.primary_rays; total.reflection_rays += s.reflection_rays; total.shadow_rays += s.shadow_rays;
     total.box_tests += s.box_tests; total.tri_tests += s.tri_tests; total.sphere_tests += s.sphere_tests;
     total.shaded_hits += s.shaded_hits; total.wave_node_steps += s.wave_node_steps; total.wave_prim_steps += s.wave_prim_steps;
+    total.wave_stage1_steps += s.wave_stage1_steps; total.wave_stage2_steps += s.wave_stage2_steps;
     total.bad_material += s.bad_material;
     if (s.kernel_ms > total.kernel_ms) total.kernel_ms = s.kernel_ms;
     if (s.upload_ms > total.upload_ms) total.upload_ms = s.upload_ms;

@@ -72,7 +72,7 @@ struct SParams {
 enum { TRAV_LANE = 1, TRAV_PACKET = 2, TRAV_ADAPTIVE = 3, TRAV_STREAM = 4 };
 
 enum { CTR_PRIMARY = 0, CTR_REFLECTION, CTR_SHADOW, CTR_SHADED, CTR_BAD_MAT,
-       CTR_BOX, CTR_TRI, CTR_SPH, CTR_WAVE_NODES, CTR_WAVE_PRIMS, CTR_COUNT,
+       CTR_BOX, CTR_TRI, CTR_SPH, CTR_WAVE_NODES, CTR_WAVE_PRIMS, CTR_WAVE_STAGE1, CTR_WAVE_STAGE2, CTR_COUNT,
        // appended after the summed counters: per-wave shader-clock statistics (collect_stats builds)
        CTR_MAX_WAVE_CYCLES = CTR_COUNT, CTR_SUM_WAVE_CYCLES, CTR_TOTAL };
 

@@ -794,3 +794,32 @@ def test_multi_object_both_transports_on_one_device(gpu):
         yahr_amd.MultiContext(scene, yahr_amd.device_count() + 1)
     with pytest.raises(yahr_amd.YahrError):
         yahr_amd.MultiContext(scene, 2, devices=[0, 0])
+
+
+def test_stream_form_in_row_bands(gpu, monkeypatch):
+    """The wavefront form processes the image in bands of tile rows so that its queues stay below a memory budget.
+    With the budget forced down to a few tile rows (YAHR_STREAM_BUDGET_KB) the image and every counter must still equal
+    the packet walker's: one pixel per lane, samples in lanes (2x2-pixel and 1-pixel tiles), ragged last band, row
+    shards and frame batches."""
+    import torch
+    d = scenes.pseudo_bunny(203, 117, n_lon=48, n_lat=25, depth=3)
+    scene = d.to_scene().build()
+    for spp, kb in ((1, 700), (16, 2500), (64, 3000), (5, 2000)):
+        ref, st0 = yahr_amd.render_image(scene, spp=spp, seed=2, traverse=yahr_amd.TRAVERSE_PACKET, collect_stats=True)
+        monkeypatch.setenv("YAHR_STREAM_BUDGET_KB", str(kb))
+        img, st1 = yahr_amd.render_image(scene, spp=spp, seed=2, traverse=yahr_amd.TRAVERSE_STREAM, collect_stats=True)
+        assert np.array_equal(bits(img), bits(ref)), (spp, kb)
+        for k in COUNT_KEYS:
+            assert st0[k] == st1[k], (k, spp)
+        ctx = yahr_amd.Context(scene, 0)
+        part = ctx.render(n_shards=3, shard=1, strip_rows=8, spp=spp, seed=2, traverse=yahr_amd.TRAVERSE_STREAM)
+        rows = yahr_amd.shard_global_rows(scene.height, 3, 1, 8)
+        batch = ctx.render(frames=2, spp=spp, seed=2, traverse=yahr_amd.TRAVERSE_STREAM).cpu().numpy()
+        torch.cuda.synchronize()
+        assert np.array_equal(bits(part.cpu().numpy()[: len(rows)]), bits(ref[rows]))
+        assert np.array_equal(bits(batch[0]), bits(ref)) and np.array_equal(bits(batch[1]), bits(ref))
+        ctx.close()
+        monkeypatch.delenv("YAHR_STREAM_BUDGET_KB")
+    monkeypatch.setenv("YAHR_STREAM_BUDGET_KB", "1")                     # not even one tile row: explicit STREAM is an error,
+    with pytest.raises(yahr_amd.YahrError):                               # AUTO would fall back to the fused kernel
+        yahr_amd.render_image(scene, traverse=yahr_amd.TRAVERSE_STREAM)

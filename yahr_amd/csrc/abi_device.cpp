@@ -312,14 +312,29 @@ static int ensure_windows(yahr_ctx *c, int n_batches) {
 // bytes per sample of a pass: two ping-pong path queues of 64 B, (w_k, D_k) of every level, the level count
 static size_t stream_bytes_per_sample(int depth) { return 2 * 64 + (size_t)depth * 32 + 1; }
 
-// Can a pass of n_samples be laid out in this device's memory?  (AUTO falls back to the fused kernel if not.)
-static bool stream_fits(yahr_ctx *c, size_t n_samples, int depth) {
-  const size_t need = n_samples * stream_bytes_per_sample(depth) + 4096;
-  if (n_samples == 0 || n_samples > 0x7fffffffULL) return false;
-  if (need <= c->stream_bytes) return true;
+// The image is processed in BANDS of whole tile rows so that the queues of one pass stay below a budget: an eighth of
+// the device memory that is free (never more than 16 GiB; what this context already holds for the purpose counts as
+// free), at least one tile row.  Returns the rows per band (a multiple of tile_h), 0 if even one tile row does not fit.
+static int stream_band_rows(yahr_ctx *c, int n_local_rows, int tile_h, int spp, int depth) {
   size_t fr = 0, tot = 0;
-  if (hipMemGetInfo(&fr, &tot) != hipSuccess) return false;
-  return need <= (fr + c->stream_bytes) / 10 * 6;                          // leave 40 % of what is free to the caller
+  if (hipMemGetInfo(&fr, &tot) != hipSuccess) return 0;
+  size_t budget = (fr + c->stream_bytes) / 8;
+  const size_t cap = (size_t)16 << 30;
+  if (budget > cap) budget = cap;
+  if (budget < c->stream_bytes) budget = c->stream_bytes;
+  if (const char *e = std::getenv("YAHR_STREAM_BUDGET_KB")) {               // tests: force several bands on a small image
+    const long v = std::atol(e);
+    if (v > 0) budget = (size_t)v << 10;
+  }
+  const size_t per_tile_row = (size_t)tile_h * (size_t)c->width * (size_t)spp * stream_bytes_per_sample(depth);
+  if (per_tile_row == 0 || per_tile_row + 4096 > budget) return 0;
+  size_t k = (budget - 4096) / per_tile_row;
+  const size_t max_samples = 0x7fffffffULL / ((size_t)tile_h * (size_t)c->width * (size_t)spp);      // sample ids are 31-bit
+  if (k > max_samples) k = max_samples;
+  if (k == 0) return 0;
+  const size_t total = ((size_t)n_local_rows + (size_t)tile_h - 1) / (size_t)tile_h;
+  if (k > total) k = total;
+  return (int)(k * (size_t)tile_h);
 }
 
 // like ensure_windows: allocates on the first use of a configuration (warm it up once before a graph capture)
@@ -420,14 +435,15 @@ int yahr_ctx_render(yahr_ctx *c, int32_t row0, int32_t row1, const yahr_render_o
     n_blocks *= rp.frames;
   }
   int mode = pick_mode(o.traverse, c->auto_mode);
+  int band_rows = 0, tile_h = 1;
   if (mode == TRAV_STREAM) {
-    // one pass per frame of the batch: camera-ray launch, one launch per recursion level, resolve
-    const size_t n_samples = (size_t)rp.n_local_rows * (size_t)c->width * (size_t)o.spp;
-    const bool can = rp.tile_mode == 0 && !regroup && rp.row_order == nullptr && !rp.xcd_swizzle && stream_fits(c, n_samples, c->ds.depth);
-    if (!can) {
+    // per frame of the batch and per band of rows: camera-ray launch, one launch per recursion level, resolve
+    tile_h = (64 >> rp.sil_log2) >> rp.pw_log2;
+    const bool can = rp.tile_mode == 0 && !regroup && rp.row_order == nullptr && !rp.xcd_swizzle;
+    if (can) band_rows = stream_band_rows(c, rp.n_local_rows, tile_h, o.spp, c->ds.depth);
+    if (band_rows == 0) {
       if (o.traverse == YAHR_TRAVERSE_STREAM) {
-        set_error("stream traversal needs wave tiles, no tuning bits and " +
-                  std::to_string(n_samples * stream_bytes_per_sample(c->ds.depth) >> 20) + " MiB of free device memory");
+        set_error("stream traversal needs wave tiles, no tuning bits, and device memory for the queues of one tile row");
         return YAHR_E_ARG;
       }
       mode = TRAV_ADAPTIVE;                                                // AUTO: the fused kernel
@@ -435,8 +451,7 @@ int yahr_ctx_render(yahr_ctx *c, int32_t row0, int32_t row1, const yahr_render_o
   }
   HIP_TRY(hipEventRecord(c->ev0, st));
   if (mode == TRAV_STREAM) {
-    const size_t n_samples = (size_t)rp.n_local_rows * (size_t)c->width * (size_t)o.spp;
-    const int frames = rp.frames, tiles = n_blocks / frames;
+    const int frames = rp.frames;
     const size_t stride = rp.frame_stride;
     const DCold *cams = rp.cams;
     SParams sp{};
@@ -444,13 +459,21 @@ int yahr_ctx_render(yahr_ctx *c, int32_t row0, int32_t row1, const yahr_render_o
       for (int f = 0; f < frames; ++f)
         HIP_TRY(hipMemsetAsync(d_rgb + (size_t)f * stride, 0, sizeof(float) * 3 * (size_t)rp.n_local_rows * (size_t)c->width, st));
     } else {
-      int rc = ensure_stream(c, n_samples, c->ds.depth, sp); if (rc) return rc;
+      const size_t band_samples = (size_t)band_rows * (size_t)c->width * (size_t)o.spp;
+      int rc = ensure_stream(c, band_samples, c->ds.depth, sp); if (rc) return rc;
       rp.frames = 1; rp.cams = nullptr; rp.frame_stride = 0;
       for (int f = 0; f < frames; ++f) {
         sp.cam = cams ? cams + f : c->ds.cold;
-        HIP_TRY(hipMemsetAsync(c->d_qcount, 0, sizeof(unsigned) * (size_t)(c->ds.depth + 1), st));
-        HIP_TRY(yahr_dev::launch_stream_pass(c->ds, rp, sp, c->stream_secondary, tiles, d_rgb + (size_t)f * stride, c->d_ctr,
-                                             o.collect_stats != 0, st));
+        for (int lv0 = 0; lv0 < rp.n_local_rows; lv0 += band_rows) {
+          sp.lv0 = lv0;
+          sp.band_rows = std::min(band_rows, rp.n_local_rows - lv0);
+          sp.tile0 = (lv0 / tile_h) * rp.tiles_x;
+          const int band_tiles = ((sp.band_rows + tile_h - 1) / tile_h) * rp.tiles_x;
+          HIP_TRY(hipMemsetAsync(c->d_qcount, 0, sizeof(unsigned) * (size_t)(c->ds.depth + 1), st));
+          HIP_TRY(yahr_dev::launch_stream_pass(c->ds, rp, sp, c->stream_secondary, band_tiles,
+                                               d_rgb + (size_t)f * stride + (size_t)lv0 * (size_t)c->width * 3, c->d_ctr,
+                                               o.collect_stats != 0, st));
+        }
       }
     }
   } else {

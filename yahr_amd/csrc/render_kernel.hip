@@ -752,14 +752,15 @@ void k_stream_primary(DScene sc_in, YD_SCENE_PARAMS, RParams rp, SParams sp, uns
   Counters c = {};
   bool bad_mat = false;
   int u, gv; size_t row; bool valid;
-  wave_tile_pixel(rp, (int)blockIdx.x, lane, u, gv, row, valid);
+  wave_tile_pixel(rp, sp.tile0 + (int)blockIdx.x, lane, u, gv, row, valid);
+  valid = valid && row < (size_t)(sp.lv0 + sp.band_rows);
   const int sw = 1 << rp.sil_log2, j0 = lane & (sw - 1);
   for (int s0 = 0; s0 < rp.spp; s0 += sw) {
     float du = 0.0f, dv = 0.0f;                        // spp == 1: the integer pixel corner (main.hs:73)
     if (rp.spp > 1) sample_offset(u, gv, s0 + j0, rp.n_strata, rp.seed, du, dv);
     V3 ro, rd;
     camera_ray(sp.cam, (float)u + du, (float)gv + dv, ro, rd);
-    const int sid = (int)((row * (size_t)rp.width + (size_t)u) * (size_t)rp.spp) + s0 + j0;
+    const int sid = (int)(((row - (size_t)sp.lv0) * (size_t)rp.width + (size_t)u) * (size_t)rp.spp) + s0 + j0;   // band-local
     if (STATS) c.primary += lanes(valid);
     Hit hit;
     traverse<TRAV_PACKET, STATS>(sc, valid, false, true, ro, rd, 1e6f, hit, c);
@@ -855,8 +856,8 @@ void k_stream_level(DScene sc_in, YD_SCENE_PARAMS, SParams sp, unsigned long lon
 // per pixel: every sample's levels folded back to front (v = w_k * v + D_k: `(n .* r) @* f r * rs + direct`,
 // Integrators.hs:37), the samples added in sample order from 0, times 1/spp -- the fused kernel's arithmetic
 __global__ __launch_bounds__(256) void k_stream_resolve(RParams rp, SParams sp, int depth, float *__restrict__ out) {
-  const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (p >= (size_t)rp.n_local_rows * (size_t)rp.width) return;
+  const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;                 // pixel of the band; `out` points at the band
+  if (p >= (size_t)sp.band_rows * (size_t)rp.width) return;
   V3 acc = vof(0.0f);
   for (int s = 0; s < rp.spp; ++s) {
     const size_t sid = p * (size_t)rp.spp + (size_t)s;
@@ -966,7 +967,7 @@ hipError_t launch_stream_pass(const DScene &sc, const RParams &rp, SParams sp, i
   if (secondary_mode == TRAV_LANE) launch_stream_levels<TRAV_LANE>(sc, sp, n_level_blocks, ctr, stats, st);
   else if (secondary_mode == TRAV_PACKET) launch_stream_levels<TRAV_PACKET>(sc, sp, n_level_blocks, ctr, stats, st);
   else launch_stream_levels<TRAV_ADAPTIVE>(sc, sp, n_level_blocks, ctr, stats, st);
-  const size_t n_px = (size_t)rp.n_local_rows * (size_t)rp.width;
+  const size_t n_px = (size_t)sp.band_rows * (size_t)rp.width;
   hipLaunchKernelGGL(k_stream_resolve, dim3((unsigned)((n_px + 255) / 256)), dim3(256), 0, st, rp, sp, sc.depth, out);
   return hipGetLastError();
 }

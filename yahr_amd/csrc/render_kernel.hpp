@@ -64,7 +64,8 @@ struct SParams {
   unsigned *count;                         // [depth + 1] queue lengths
   float4 *lev;                             // [(2 k + {0: w_k, 1: D_k}) * capacity + sample id]
   unsigned char *levels;                   // [capacity] number of levels whose ray hit something, per sample
-  unsigned capacity;                       // samples of this pass = local rows x width x spp
+  unsigned capacity;                       // samples of this pass = band rows x width x spp
+  int tile0, lv0, band_rows;               // the pass covers the wave tiles from tile0 on = local rows [lv0, lv0 + band_rows)
   const DCold *cam;                        // camera of this pass
   int level, last;                         // k_stream_level: recursion level k, and whether it is the last one
 };

@@ -659,16 +659,18 @@ def test_extreme_operands_walkers_agree(gpu, bvh_depth):
     ctx.close()
 
 
-def test_render_can_be_captured_in_a_hip_graph(gpu):
+@pytest.mark.parametrize("mode", [yahr_amd.TRAVERSE_AUTO, yahr_amd.TRAVERSE_STREAM])
+def test_render_can_be_captured_in_a_hip_graph(gpu, mode):
     """yahr_ctx_render is asynchronous on the caller's stream and allocation-free after the first use of a
-    configuration: capture it once, replay it, get the same bits."""
+    configuration: capture it once, replay it, get the same bits.  Also for the wavefront
+    form, whose launches (camera rays, one per recursion level, resolve) and counter resets all go to that stream."""
     import torch
     d = scenes.pseudo_bunny(160, 96, n_lon=40, n_lat=20)
     scene = d.to_scene().build()
     ref, _ = yahr_amd.render_image(scene)
     ctx = yahr_amd.Context(scene, 0)
     out = torch.zeros((2, scene.height, scene.width, 3), device="cuda:0")
-    o = yahr_amd.make_opts(frames=2)
+    o = yahr_amd.make_opts(frames=2, traverse=mode)
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):

@@ -131,13 +131,16 @@ def cpu_baseline(desc, cores, spp=1, min_cpu_seconds=10.0):
 
 
 def load_profile(workload):
-    """Per-frame counter figures of the committed rocprofv3 PMC profile of this workload (profiles/
-    traffic_latest.json, written by tools/pmc_to_traffic.py from separate --pmc passes), or None."""
-    try:
-        j = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
-        return j if j.get("workload") == workload and "valu_insts_per_frame" in j else None
-    except (OSError, ValueError):
-        return None
+    """Per-frame counter figures of the committed rocprofv3 PMC profile of this workload (profiles/traffic_<workload>.json;
+    traffic_latest.json for the headline workload; written by tools/pmc_to_traffic.py from separate --pmc passes), or None."""
+    for name in ("traffic_%s.json" % workload, "traffic_latest.json"):
+        try:
+            j = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if j.get("workload") == workload and "valu_insts_per_frame" in j:
+                return j
+        except (OSError, ValueError):
+            pass
+    return None
 
 
 def main():
@@ -306,8 +309,8 @@ def main():
         my_px = yahr_amd.shard_rows(h, world, rank, args.strip_rows) * w
         alg = algorithmic_bytes(st_full, scene.n_lights, F * my_px)      # of this rank's F-frame launch
         prof = load_profile(args.workload) if world == 1 else None
-        roof = {"kernel": "k_render", "kernel_ms_avg": round(kernel_ms_avg, 4), "frames_per_launch": F,
-                "launches_timed": len(kern_ms)}
+        roof = {"kernel": (prof or {}).get("kernels", "k_render"), "kernel_ms_avg": round(kernel_ms_avg, 4),
+                "frames_per_launch": F, "launches_timed": len(kern_ms)}
         if prof is not None and kern_ms:
             # what the counters say bounds the kernel: vector-instruction issue.  Instruction
             # counts are deterministic per frame, so the profile's per-frame figures (mean over the cameras of the

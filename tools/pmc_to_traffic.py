@@ -1,27 +1,40 @@
-"""profiles/traffic_latest.json from a pmc_summary.txt of tools/profile_bench.sh: per-FRAME counter figures of the
-timed F-frame launches (instruction counts are deterministic per frame; the mean over the F cameras of bench.py's
-orbit is what is stored), which bench.py scales by its frames per launch.
-usage: pmc_to_traffic.py <pmc_summary.txt> <workload> <frames per launch> <source text> > profiles/traffic_latest.json"""
-import json, sys
-vals = {}
-import re
+"""Per-FRAME counter figures of a workload from a pmc_summary.txt of tools/profile_bench.sh, for bench.py's roofline:
+instruction counts are deterministic per frame (the mean over the F cameras of bench.py's orbit is what is stored),
+so bench.py scales them by its frames per launch.
+  packet / lane / adaptive kernels: one k_render launch holds F frames      -> per frame = mean per launch / F
+  wavefront form: per frame one k_stream_primary, `depth` k_stream_level and one k_stream_resolve launch
+                                                                             -> per frame = primary + depth x level + resolve
+usage: pmc_to_traffic.py <pmc_summary.txt> <workload> <frames per launch> <source text> [stream depth] > profiles/traffic_<workload>.json"""
+import collections, json, re, sys
+vals = collections.defaultdict(dict)          # kernel -> counter -> mean per dispatch (largest grid)
 for line in open(sys.argv[1]):
-    m = re.match(r"^(k_render.*?)\s{2,}(\S+)\s+grid=.*mean=\s*([0-9.eE+-]+)", line)   # rows: kernel  counter  grid=.. n=.. mean=..
+    m = re.match(r"^(k_\S.*?)\s{2,}(\S+)\s+grid=\s*(\d+)\s+n=.*mean=\s*([0-9.eE+-]+)", line)
     if m:
-        vals[m.group(2)] = float(m.group(3))
+        vals[m.group(1).split("<")[0]][m.group(2)] = float(m.group(4))
 workload, F, source = sys.argv[2], int(sys.argv[3]), sys.argv[4]
-fetch_kb, write_kb = vals["FETCH_SIZE"], vals["WRITE_SIZE"]
+depth = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+
+
+def per_frame(counter):
+    if depth:                                   # wavefront form
+        return (vals["k_stream_primary"].get(counter, 0.0) + depth * vals["k_stream_level"].get(counter, 0.0)
+                + vals["k_stream_resolve"].get(counter, 0.0))
+    return vals["k_render"].get(counter, 0.0) / F
+
+
+fetch_kb, write_kb = per_frame("FETCH_SIZE"), per_frame("WRITE_SIZE")
 out = {
     "workload": workload, "frames_per_launch_profiled": F, "source": source,
-    "valu_insts_per_frame": vals["SQ_INSTS_VALU"] / F,
-    "salu_insts_per_frame": vals["SQ_INSTS_SALU"] / F,
-    "smem_insts_per_frame": vals["SQ_INSTS_SMEM"] / F,
-    "branch_insts_per_frame": vals.get("SQ_INSTS_BRANCH", 0.0) / F,
-    "FETCH_SIZE_KB_raw_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
+    "kernels": ("k_stream_primary + %d x k_stream_level + k_stream_resolve per frame" % depth) if depth else "k_render, %d frames per launch" % F,
+    "valu_insts_per_frame": per_frame("SQ_INSTS_VALU"),
+    "salu_insts_per_frame": per_frame("SQ_INSTS_SALU"),
+    "smem_insts_per_frame": per_frame("SQ_INSTS_SMEM"),
+    "vmem_rd_insts_per_frame": per_frame("SQ_INSTS_VMEM_RD"),
+    "FETCH_SIZE_KB_raw_per_frame": fetch_kb, "WRITE_SIZE_KB_per_frame": write_kb,
     "correction": "gfx950: FETCH_SIZE x2 (MI355X_MICROARCH.md, HBM section: the counter tallies 128-B requests at 64 B; "
-                  "calibrated there for 16 B/lane streams, uncalibrated for this kernel's scalar record fetches, so the "
+                  "calibrated there for 16 B/lane streams, uncalibrated for scalar record fetches and 32-byte gathers, so the "
                   "doubled figure is an upper bound); WRITE_SIZE taken as is",
-    "hbm_bytes_per_frame": (2.0 * fetch_kb + write_kb) * 1024.0 / F,
+    "hbm_bytes_per_frame": (2.0 * fetch_kb + write_kb) * 1024.0,
     "valu_issue_peak_measured_ginst_s": 1000.0,
     "valu_issue_peak_measured_source": "tools/ubench/valu_rate.hip on MI355X (round 1): 982-1015 G wave64 f32 instr/s chip-wide at "
                                        ">= 2 waves/SIMD (2.45 clocks per instruction per SIMD)",

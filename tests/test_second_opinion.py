@@ -94,3 +94,38 @@ def test_second_restatement_reproduces_the_spec_triangle_kat():
         if hit:
             assert abs(float(h[0]) - 5.0) < 1e-4 and h[2] == 7
             assert np.allclose(h[1]["point"], (x, y, 5), atol=1e-4) and np.allclose(h[1]["normal"], (0, 0, -1))
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_random_scenes_oracle_vs_second_restatement(seed):
+    """seeded random scenes (spheres and triangles with random, un-normalised vertex normals, 0-3 lights, depth 1-4,
+    random Blinn materials): the two restatements agree bit for bit up to the ulp of `**`"""
+    rng = np.random.default_rng(seed)
+    mats = [scenes._mat("m%d" % i, (0, 0, 0), tuple(rng.uniform(0.1, 0.9, 3)), tuple(rng.uniform(0.0, 0.8, 3)),
+                        float(rng.choice([1, 2.5, 8, 30]))) for i in range(3)]
+    objs = []
+    for _ in range(int(rng.integers(2, 6))):
+        objs.append(("sphere", tuple(rng.uniform(-3, 3, 3) + (0, 0, 7)), float(rng.uniform(0.4, 1.4)), "m%d" % rng.integers(3)))
+    for _ in range(int(rng.integers(4, 12))):
+        c = rng.uniform(-3, 3, 3) + (0, 0, 7)
+        p = [tuple(c + rng.uniform(-2.5, 2.5, 3)) for _ in range(3)]
+        nrm = [tuple(rng.normal(size=3) * rng.uniform(0.5, 1.5)) for _ in range(3)]
+        objs.append(("triangle", p[0], p[1], p[2], nrm[0], nrm[1], nrm[2], "m%d" % rng.integers(3)))
+    lights = [(tuple(rng.uniform(-6, 6, 3) + (0, 5, 0)), tuple(rng.uniform(10, 120, 3))) for _ in range(int(rng.integers(0, 4)))]
+    cam = dict(imW=14, imH=10, focal=float(rng.uniform(0.8, 2.0)), look=tuple(rng.uniform(-0.2, 0.2, 2)) + (1.0,),
+               up=(0, 1, 0), pos=tuple(rng.uniform(-1, 1, 3)))
+    d = scenes.SceneDesc(int(rng.integers(1, 5)), 0, "Midpoint", cam, mats, lights, objs)
+    osc = OracleScene.from_desc(d).build()
+    s2 = expand(d)
+    n_nonzero = 0
+    for v in range(10):
+        for u in range(14):
+            ray = osc.camera_ray(u, v)
+            want = osc.radiance(ray)
+            got = np.array(so.radiance(s2, (so.vec(*ray[0:3]), so.vec(*ray[3:6]), F(ray[6]))), dtype=F)
+            n_nonzero += bool(want.any())
+            if not np.array_equal(got.view(np.uint32), want.view(np.uint32)):
+                both_nan = np.isnan(got) & np.isnan(want)
+                rel = np.abs(got.astype(np.float64) - want) / np.maximum(np.abs(want), 1e-30)
+                assert np.all((rel < 3e-7) | both_nan), (seed, u, v, got, want)
+    assert n_nonzero > 5 or len(lights) == 0

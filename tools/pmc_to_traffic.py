@@ -36,8 +36,8 @@ out = {
                   "doubled figure is an upper bound); WRITE_SIZE taken as is",
     "hbm_bytes_per_frame": (2.0 * fetch_kb + write_kb) * 1024.0,
     "valu_issue_peak_measured_ginst_s": 1000.0,
-    "valu_issue_peak_measured_source": "tools/ubench/valu_rate.hip on MI355X (round 1): 982-1015 G wave64 f32 instr/s chip-wide at "
-                                       ">= 2 waves/SIMD (2.45 clocks per instruction per SIMD)",
+    "valu_issue_peak_measured_source": "tools/ubench/run_valu_rate.sh on MI355X (profiles/r02_valu_rate.txt): 984-1019 G wave64 f32 instr/s "
+                                       "chip-wide at 2-8 waves/SIMD; the chip holds 2.13-2.16 GHz under that load, i.e. 2.18-2.23 cycles per instruction per SIMD",
 }
 json.dump(out, sys.stdout, indent=1)
 print()

@@ -43,7 +43,7 @@ std::vector<yahr::SceneObject> &target_list(HostScene &hs) {
 extern "C" {
 
 const char *yahr_last_error(void) { return yahr::g_last_error.c_str(); }
-const char *yahr_version(void) { return "yahr_hip 0.1 (gfx950)"; }
+const char *yahr_version(void) { return "yahr_hip 0.2 (gfx950)"; }
 
 int yahr_scene_parse(const char *text, size_t len, int lenient, yahr_host_scene **out) {
   if (!text || !out) { set_error("null argument"); return YAHR_E_ARG; }

@@ -360,9 +360,11 @@ def test_frame_batch_equals_single_frames(gpu):
     cams = [dict(d.camera, pos=(-4 + 0.5 * i, 3, 2), look=(0.4, -0.3 - 0.02 * i, 1)) for i in range(4)]
     ctx.set_cameras([[c["imW"], c["imH"], c["focal"], *c["look"], *c["up"], *c["pos"]] for c in cams])
     batch = ctx.render(frames=4).cpu().numpy()
+    batch_stream = ctx.render(frames=4, traverse=yahr_amd.TRAVERSE_STREAM).cpu().numpy()      # one pass per frame and camera
     for i, c in enumerate(cams):
         ref_img, _ = yahr_amd.render_image(d.with_camera(**c).to_scene().build())
         assert np.array_equal(bits(batch[i]), bits(ref_img)), i
+        assert np.array_equal(bits(batch_stream[i]), bits(ref_img)), i
         oref, _ = oracle_render(d.with_camera(**c))
         assert outside_tol(batch[i], oref) == 0
     with pytest.raises(yahr_amd.YahrError):

@@ -808,7 +808,7 @@ def test_stream_form_in_row_bands(gpu, monkeypatch):
     import torch
     d = scenes.pseudo_bunny(203, 117, n_lon=48, n_lat=25, depth=3)
     scene = d.to_scene().build()
-    for spp, kb in ((1, 700), (16, 2500), (64, 3000), (5, 2000)):
+    for spp, kb in ((1, 1000), (16, 7000), (64, 11000), (5, 7000)):
         ref, st0 = yahr_amd.render_image(scene, spp=spp, seed=2, traverse=yahr_amd.TRAVERSE_PACKET, collect_stats=True)
         monkeypatch.setenv("YAHR_STREAM_BUDGET_KB", str(kb))
         img, st1 = yahr_amd.render_image(scene, spp=spp, seed=2, traverse=yahr_amd.TRAVERSE_STREAM, collect_stats=True)

@@ -309,8 +309,10 @@ static int ensure_windows(yahr_ctx *c, int n_batches) {
 }
 
 // ---- wavefront ("stream") form ------------------------------------------------------------------------
-// bytes per sample of a pass: two ping-pong path queues of 64 B, (w_k, D_k) of every level, the level count
-static size_t stream_bytes_per_sample(int depth) { return 2 * 64 + (size_t)depth * 32 + 1; }
+// bytes per sample of a pass: two ping-pong path queues of 64 B, (w_k, D_k) of every level, the level count, and the
+// Morton cell + sorted position of a queue entry (4 B each); the cell histogram of the sort comes on top once
+static size_t stream_bytes_per_sample(int depth) { return 2 * 64 + (size_t)depth * 32 + 1 + 8; }
+static size_t stream_fixed_bytes(int depth) { return sizeof(unsigned) * YD_SORT_CELLS * (size_t)(depth + 1) + 4096; }
 
 // The image is processed in BANDS of whole tile rows so that the queues of one pass stay below a budget: an eighth of
 // the device memory that is free (never more than 16 GiB; what this context already holds for the purpose counts as
@@ -327,8 +329,8 @@ static int stream_band_rows(yahr_ctx *c, int n_local_rows, int tile_h, int spp, 
     if (v > 0) budget = (size_t)v << 10;
   }
   const size_t per_tile_row = (size_t)tile_h * (size_t)c->width * (size_t)spp * stream_bytes_per_sample(depth);
-  if (per_tile_row == 0 || per_tile_row + 4096 > budget) return 0;
-  size_t k = (budget - 4096) / per_tile_row;
+  if (per_tile_row == 0 || per_tile_row > budget) return 0;              // (the cell counts, stream_fixed_bytes, come on top)
+  size_t k = budget / per_tile_row;
   const size_t max_samples = 0x7fffffffULL / ((size_t)tile_h * (size_t)c->width * (size_t)spp);      // sample ids are 31-bit
   if (k > max_samples) k = max_samples;
   if (k == 0) return 0;
@@ -339,7 +341,7 @@ static int stream_band_rows(yahr_ctx *c, int n_local_rows, int tile_h, int spp, 
 
 // like ensure_windows: allocates on the first use of a configuration (warm it up once before a graph capture)
 static int ensure_stream(yahr_ctx *c, size_t n_samples, int depth, SParams &sp) {
-  const size_t need = n_samples * stream_bytes_per_sample(depth) + 4096;
+  const size_t need = n_samples * stream_bytes_per_sample(depth) + stream_fixed_bytes(depth);
   if (need > c->stream_bytes) {
     if (c->d_stream) { HIP_TRY(hipFree(c->d_stream)); c->d_stream = nullptr; c->stream_bytes = 0; }
     HIP_TRY(dev_alloc(&c->d_stream, need));
@@ -358,6 +360,9 @@ static int ensure_stream(yahr_ctx *c, size_t n_samples, int depth, SParams &sp) 
     sp.qd[s] = (float4 *)p; p += 16 * n_samples;
   }
   sp.lev = (float4 *)p; p += 32 * (size_t)depth * n_samples;
+  sp.cell = (unsigned *)p; p += 4 * n_samples;
+  sp.perm = (unsigned *)p; p += 4 * n_samples;
+  sp.hist = (unsigned *)p; p += sizeof(unsigned) * YD_SORT_CELLS * (size_t)(depth + 1);
   sp.levels = (unsigned char *)p;
   sp.count = c->d_qcount;
   sp.capacity = (unsigned)n_samples;
@@ -470,6 +475,7 @@ int yahr_ctx_render(yahr_ctx *c, int32_t row0, int32_t row1, const yahr_render_o
           sp.tile0 = (lv0 / tile_h) * rp.tiles_x;
           const int band_tiles = ((sp.band_rows + tile_h - 1) / tile_h) * rp.tiles_x;
           HIP_TRY(hipMemsetAsync(c->d_qcount, 0, sizeof(unsigned) * (size_t)(c->ds.depth + 1), st));
+          HIP_TRY(hipMemsetAsync(sp.hist, 0, sizeof(unsigned) * YD_SORT_CELLS * (size_t)(c->ds.depth + 1), st));
           HIP_TRY(yahr_dev::launch_stream_pass(c->ds, rp, sp, c->stream_secondary, band_tiles,
                                                d_rgb + (size_t)f * stride + (size_t)lv0 * (size_t)c->width * 3, c->d_ctr,
                                                o.collect_stats != 0, st));

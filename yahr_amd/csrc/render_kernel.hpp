@@ -68,7 +68,14 @@ struct SParams {
   int tile0, lv0, band_rows;               // the pass covers the wave tiles from tile0 on = local rows [lv0, lv0 + band_rows)
   const DCold *cam;                        // camera of this pass
   int level, last;                         // k_stream_level: recursion level k, and whether it is the last one
+  // order of the level launch: the queued paths sorted by the Morton cell of their hit point (counting sort, below)
+  unsigned *cell;                          // [capacity] Morton cell of queue entry e (of the queue being filled)
+  unsigned *perm;                          // [capacity] queue entry handled by lane e of the level launch
+  unsigned *hist;                          // [depth + 1][YD_SORT_CELLS] entries per cell of queue k, then (exclusive scan) first slot of a cell;
+                                           // zeroed by the caller with the queue lengths
 };
+#define YD_SORT_BITS 18                    // 6 bits per axis: 64^3 cells of the root box
+#define YD_SORT_CELLS (1u << YD_SORT_BITS)
 
 enum { TRAV_LANE = 1, TRAV_PACKET = 2, TRAV_ADAPTIVE = 3, TRAV_STREAM = 4 };
 

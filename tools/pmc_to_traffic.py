@@ -2,8 +2,8 @@
 instruction counts are deterministic per frame (the mean over the F cameras of bench.py's orbit is what is stored),
 so bench.py scales them by its frames per launch.
   packet / lane / adaptive kernels: one k_render launch holds F frames      -> per frame = mean per launch / F
-  wavefront form: per frame one k_stream_primary, `depth` k_stream_level and one k_stream_resolve launch
-                                                                             -> per frame = primary + depth x level + resolve
+  wavefront form: per frame one k_stream_primary, `depth` x (k_sort_scan, k_sort_scatter, k_stream_level) and one
+  k_stream_resolve launch                       -> per frame = primary + depth x (scan + scatter + level) + resolve
 usage: pmc_to_traffic.py <pmc_summary.txt> <workload> <frames per launch> <source text> [stream depth] > profiles/traffic_<workload>.json"""
 import collections, json, re, sys
 vals = collections.defaultdict(dict)          # kernel -> counter -> mean per dispatch (largest grid)
@@ -17,15 +17,16 @@ depth = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 
 def per_frame(counter):
     if depth:                                   # wavefront form
-        return (vals["k_stream_primary"].get(counter, 0.0) + depth * vals["k_stream_level"].get(counter, 0.0)
-                + vals["k_stream_resolve"].get(counter, 0.0))
+        return (vals["k_stream_primary"].get(counter, 0.0) + vals["k_stream_resolve"].get(counter, 0.0)
+                + depth * (vals["k_stream_level"].get(counter, 0.0) + vals["k_sort_scan"].get(counter, 0.0)
+                           + vals["k_sort_scatter"].get(counter, 0.0)))
     return vals["k_render"].get(counter, 0.0) / F
 
 
 fetch_kb, write_kb = per_frame("FETCH_SIZE"), per_frame("WRITE_SIZE")
 out = {
     "workload": workload, "frames_per_launch_profiled": F, "source": source,
-    "kernels": ("k_stream_primary + %d x k_stream_level + k_stream_resolve per frame" % depth) if depth else "k_render, %d frames per launch" % F,
+    "kernels": ("k_stream_primary + %d x (k_sort_scan + k_sort_scatter + k_stream_level) + k_stream_resolve per frame" % depth) if depth else "k_render, %d frames per launch" % F,
     "valu_insts_per_frame": per_frame("SQ_INSTS_VALU"),
     "salu_insts_per_frame": per_frame("SQ_INSTS_SALU"),
     "smem_insts_per_frame": per_frame("SQ_INSTS_SMEM"),

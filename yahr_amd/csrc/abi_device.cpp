@@ -27,8 +27,9 @@ struct yahr_ctx {
   DCold *d_cams = nullptr; int n_cams = 0;
   int *d_row_order = nullptr; int row_order_n = 0;
   int auto_mode = TRAV_PACKET;
-  int stream_secondary = TRAV_ADAPTIVE;   // walker of the secondary rays in the stream form (measured on 1 M triangles, 16 spp:
-                                          // adaptive 47.9 ms = lane 47.9 ms, packet 77.8 ms)
+  int stream_secondary = TRAV_ADAPTIVE;   // walker of the secondary rays in the stream form (measured on 1 M triangles, 16 spp,
+                                          // paths in Morton order: adaptive 38.3 ms, packet 39.7, lane 41.7; in image order
+                                          // adaptive 47.9 = lane 47.9, packet 77.8)
   unsigned long long *d_ctr = nullptr;
   int4 *d_windows = nullptr; int n_windows = 0, n_chunks = 0, windows_w = 0, windows_h = 0;
   // wavefront ("stream") form: path queues, per-level results, queue lengths (allocated on first use, grown on demand)
@@ -311,8 +312,8 @@ static int ensure_windows(yahr_ctx *c, int n_batches) {
 // ---- wavefront ("stream") form ------------------------------------------------------------------------
 // bytes per sample of a pass: two ping-pong path queues of 64 B, (w_k, D_k) of every level, the level count, and the
 // Morton cell + sorted position of a queue entry (4 B each); the cell histogram of the sort comes on top once
-static size_t stream_bytes_per_sample(int depth) { return 2 * 64 + (size_t)depth * 32 + 1 + 8; }
-static size_t stream_fixed_bytes(int depth) { return sizeof(unsigned) * YD_SORT_CELLS * (size_t)(depth + 1) + 4096; }
+static size_t stream_bytes_per_sample(int depth) { return 2 * 64 + (size_t)depth * 32 + 1 + 12; }
+static size_t stream_fixed_bytes(int depth) { return sizeof(unsigned) * YD_SORT_CELLS * (size_t)(depth + 2) + 4096; }
 
 // The image is processed in BANDS of whole tile rows so that the queues of one pass stay below a budget: an eighth of
 // the device memory that is free (never more than 16 GiB; what this context already holds for the purpose counts as
@@ -360,9 +361,10 @@ static int ensure_stream(yahr_ctx *c, size_t n_samples, int depth, SParams &sp) 
     sp.qd[s] = (float4 *)p; p += 16 * n_samples;
   }
   sp.lev = (float4 *)p; p += 32 * (size_t)depth * n_samples;
-  sp.cell = (unsigned *)p; p += 4 * n_samples;
+  sp.cell = (uint2 *)p; p += 8 * n_samples;
   sp.perm = (unsigned *)p; p += 4 * n_samples;
   sp.hist = (unsigned *)p; p += sizeof(unsigned) * YD_SORT_CELLS * (size_t)(depth + 1);
+  sp.start = (unsigned *)p; p += sizeof(unsigned) * YD_SORT_CELLS;
   sp.levels = (unsigned char *)p;
   sp.count = c->d_qcount;
   sp.capacity = (unsigned)n_samples;

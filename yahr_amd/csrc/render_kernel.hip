@@ -735,27 +735,46 @@ YD unsigned sort_cell(const DScene &sc, V3 p) {
   return (part1by2(ix) | (part1by2(iy) << 1) | (part1by2(iz) << 2)) & (YD_SORT_CELLS - 1u);
 }
 
+#ifndef YD_CELL_GROUPS
+#define YD_CELL_GROUPS 4
+#endif
 // append the live paths of this wavefront to queue `level_out`: ballot, one atomic per wavefront, prefix count; and count
-// them into the Morton cells of their hit points (first step of the counting sort that orders the next level launch --
-// here its scattered atomics hide behind the traversal work of the producing launch)
+// and rank them inside the Morton cells of their hit points (first step of the counting sort that orders the next level
+// launch -- here its scattered atomics hide behind the traversal work of the producing launch)
 YD void q_append(const DScene &sc, const SParams &sp, int level_out, bool alive, int sid, V3 rd, V3 x, V3 n, V3 dpdu, int mat) {
   const unsigned long long m = __ballot(alive);
   if (m == 0ULL) return;                                               // wave-uniform
   const int lane = threadIdx.x & 63;
+  const unsigned long long below = (1ULL << lane) - 1ULL;
   const int leader = __ffsll((long long)m) - 1;
   unsigned base = 0;
   if (lane == leader) base = atomicAdd(&sp.count[level_out], (unsigned)__popcll(m));
+  // rank inside the cell: the lanes of a wavefront that fall into the same cell (camera rays of one 2x2-pixel tile:
+  // nearly all 64) share ONE atomic -- 64 atomics on one word from one instruction are served one after the other
+  // (returning atomics, one per lane: camera-ray launch 10.7 -> 12.6 ms).  Up to YD_CELL_GROUPS cells are grouped
+  // (wave-uniform loop), the lanes left over go on their own; all atomics are in flight together.
+  const unsigned cell = sort_cell(sc, x);
+  int owner = lane; unsigned group = 1u, before = 0u;
+  unsigned long long todo = m;
+  for (int it = 0; it < YD_CELL_GROUPS && todo != 0ULL; ++it) {
+    const int l = __ffsll((long long)todo) - 1;
+    const unsigned c0 = (unsigned)__builtin_amdgcn_readlane((int)cell, l);
+    const unsigned long long same = __ballot(alive && cell == c0) & todo;
+    if ((same >> lane) & 1ULL) { owner = l; group = (unsigned)__popcll(same); before = (unsigned)__popcll(same & below); }
+    todo &= ~same;
+  }
+  unsigned rank0 = 0;
+  if (alive && owner == lane) rank0 = atomicAdd(&sp.hist[(size_t)level_out * YD_SORT_CELLS + cell], group);
   base = (unsigned)__shfl((int)base, leader, 64);
+  rank0 = (unsigned)__shfl((int)rank0, owner, 64);
   if (alive) {
-    const unsigned i = base + (unsigned)__popcll(m & ((1ULL << lane) - 1ULL));
+    const unsigned i = base + (unsigned)__popcll(m & below);
     const int s = level_out & 1;
     sp.qa[s][i] = make_float4(x.x, x.y, x.z, __int_as_float(sid));
     sp.qb[s][i] = make_float4(n.x, n.y, n.z, __int_as_float(mat));
     sp.qc[s][i] = make_float4(dpdu.x, dpdu.y, dpdu.z, rd.x);
     sp.qd[s][i] = make_float4(rd.y, rd.z, 0.0f, 0.0f);
-    const unsigned cell = sort_cell(sc, x);
-    sp.cell[i] = cell;
-    atomicAdd(&sp.hist[(size_t)level_out * YD_SORT_CELLS + cell], 1u);
+    sp.cell[i] = make_uint2(cell, rank0 + before);                     // {cell, rank inside it}
   }
 }
 
@@ -803,32 +822,34 @@ void k_stream_primary(DScene sc_in, YD_SCENE_PARAMS, RParams rp, SParams sp, uns
 // corner of the scene and sweep through it, and shadow and reflection rays of neighbouring cells walk neighbouring
 // subtrees (1 M triangles, 16 spp: 46.5 -> 36.3 ms per frame; read through a random permutation instead: 76.5 ms; 6 bits
 // per axis are as good as 10, 4 lose half of the gain).  Three small launches whose work follows the queue's LENGTH
-// (a library radix sort would have to take its capacity): count per cell (done by the producing launch as it appends,
-// q_append), exclusive scan of the cells, scatter.  The order inside a cell is whatever the atomics give; no result
-// depends on it.
-// one workgroup: exclusive prefix sum over the cells, in place
+// (a library radix sort would have to take its capacity): count per cell and rank inside the cell (ONE returning
+// atomic per path, issued by the producing launch as it appends -- q_append -- where its latency hides behind the
+// traversals of the other wavefronts; 12 M scattered atomics in a launch of their own take 0.8-1.1 ms), exclusive scan
+// of the cells, scatter (plain stores).  The order inside a cell is whatever the atomics give; no result depends on it.
+// exclusive prefix sum over the cells, hist[level] -> start: workgroup b owns cells [1024 b, 1024 b + 1024) and adds
+// up everything in front of them itself (on average half of the 1 MB of counts, from L2), so one launch does it
 __global__ __launch_bounds__(1024) void k_sort_scan(SParams sp) {
-  __shared__ unsigned part[1024];
-  constexpr unsigned per = YD_SORT_CELLS / 1024u;
-  const unsigned t = threadIdx.x;
-  unsigned sum = 0;
-  unsigned *hist = sp.hist + (size_t)sp.level * YD_SORT_CELLS;
-  for (unsigned i = 0; i < per; ++i) sum += hist[t * per + i];
-  part[t] = sum;
+  __shared__ unsigned w_pre[16], w_own[16];
+  const unsigned t = threadIdx.x, b = blockIdx.x, lane = t & 63u, w = t >> 6;
+  const unsigned *hist = sp.hist + (size_t)sp.level * YD_SORT_CELLS;
+  unsigned pre = 0;
+  for (unsigned j = t; j < b * 1024u; j += 1024u) pre += hist[j];
+  const unsigned own = hist[b * 1024u + t];
+  unsigned inc = own;                                                  // inclusive scan inside the wavefront
+  for (int off = 1; off < 64; off <<= 1) { const unsigned v = (unsigned)__shfl_up((int)inc, off, 64); if ((int)lane >= off) inc += v; }
+  for (int off = 32; off > 0; off >>= 1) pre += (unsigned)__shfl_xor((int)pre, off, 64);
+  if (lane == 63u) w_own[w] = inc;
+  if (lane == 0u) w_pre[w] = pre;
   __syncthreads();
-  for (unsigned off = 1; off < 1024u; off <<= 1) {                     // Hillis-Steele over the 1024 partial sums
-    const unsigned v = t >= off ? part[t - off] : 0u;
-    __syncthreads();
-    part[t] += v;
-    __syncthreads();
-  }
-  unsigned run = part[t] - sum;                                        // exclusive
-  for (unsigned i = 0; i < per; ++i) { const unsigned c = hist[t * per + i]; hist[t * per + i] = run; run += c; }
+  unsigned base = 0;
+  for (unsigned k = 0; k < 16u; ++k) base += w_pre[k] + (k < w ? w_own[k] : 0u);
+  sp.start[b * 1024u + t] = base + inc - own;
 }
 __global__ __launch_bounds__(1024) void k_sort_scatter(SParams sp) {
   const unsigned e = blockIdx.x * 1024u + threadIdx.x;
   if (e >= sp.count[sp.level]) return;
-  sp.perm[atomicAdd(&sp.hist[(size_t)sp.level * YD_SORT_CELLS + sp.cell[e]], 1u)] = e;
+  const uint2 cr = sp.cell[e];
+  sp.perm[sp.start[cr.x] + cr.y] = e;
 }
 
 // The grid covers the queue's CAPACITY (its length is known on the device only); wavefronts beyond the length exit at
@@ -877,7 +898,9 @@ void k_stream_level(DScene sc_in, YD_SCENE_PARAMS, SParams sp, unsigned long lon
     }
     if (STATS) c.shadow += lanes(active);
     Hit hit;
-    traverse<MODE, STATS>(sc, active, true, false, qo, qdir, qt, hit, c);
+    // the paths of a wavefront are neighbours in space (Morton order) and a shadow ray's direction follows from its
+    // origin: coherent rays, so the adaptive walker stays a packet for them (1 M triangles: 38.3 -> 37.2 ms per frame)
+    traverse<MODE, STATS>(sc, active, true, true, qo, qdir, qt, hit, c);
     if (valid) direct = direct + ((active && hit.prim < 0) ? cv : vof(0.0f));   // sum = foldl (+) 0, light order
   }
   const V3 r = rd - scale(2.0f * dot(rd, n), n);                       // reflectionDir, Integrators.hs:46-47
@@ -1006,7 +1029,7 @@ static void launch_stream_levels(const DScene &sc, SParams sp, int n_level_block
   const unsigned sort_blocks = (sp.capacity + 1023u) / 1024u;
   for (int k = 0; k < sc.depth; ++k) {
     sp.level = k; sp.last = (k == sc.depth - 1) ? 1 : 0;
-    hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, st, sp);
+    hipLaunchKernelGGL(k_sort_scan, dim3(YD_SORT_CELLS / 1024u), dim3(1024), 0, st, sp);
     hipLaunchKernelGGL(k_sort_scatter, dim3(sort_blocks), dim3(1024), 0, st, sp);
     if (stats) hipLaunchKernelGGL((k_stream_level<MODE, true>), dim3(n_level_blocks), dim3(64 * YD_LEVEL_WAVES), 0, st, sc, sc.nodes, sc.prims, sc.normals, sp, ctr);
     else hipLaunchKernelGGL((k_stream_level<MODE, false>), dim3(n_level_blocks), dim3(64 * YD_LEVEL_WAVES), 0, st, sc, sc.nodes, sc.prims, sc.normals, sp, ctr);

@@ -69,10 +69,10 @@ struct SParams {
   const DCold *cam;                        // camera of this pass
   int level, last;                         // k_stream_level: recursion level k, and whether it is the last one
   // order of the level launch: the queued paths sorted by the Morton cell of their hit point (counting sort, below)
-  unsigned *cell;                          // [capacity] Morton cell of queue entry e (of the queue being filled)
+  uint2 *cell;                             // [capacity] {Morton cell, rank inside the cell} of queue entry e (of the queue being filled)
   unsigned *perm;                          // [capacity] queue entry handled by lane e of the level launch
-  unsigned *hist;                          // [depth + 1][YD_SORT_CELLS] entries per cell of queue k, then (exclusive scan) first slot of a cell;
-                                           // zeroed by the caller with the queue lengths
+  unsigned *hist;                          // [depth + 1][YD_SORT_CELLS] entries per cell of queue k; zeroed by the caller with the queue lengths
+  unsigned *start;                         // [YD_SORT_CELLS] first slot of a cell (exclusive scan of hist[k])
 };
 #define YD_SORT_BITS 18                    // 6 bits per axis: 64^3 cells of the root box
 #define YD_SORT_CELLS (1u << YD_SORT_BITS)

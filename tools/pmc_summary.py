@@ -1,5 +1,5 @@
 """Summarise rocprofv3 --pmc CSVs: mean counter value per dispatch, per (kernel, grid size).  By default only the
-uncounted render kernels (k_render<.., false, ..> and the k_stream_* kernels of the wavefront form) are listed; of
+uncounted render kernels (k_render<.., false, ..> and the k_stream_* and k_sort_* kernels of the wavefront form) are listed; of
 k_render only the largest grid (the F-frame launches of bench.py) unless --all-grids.
 usage: pmc_summary.py <dir with one sub-directory per pass> [--all-grids]"""
 import collections, csv, glob, re, sys
@@ -9,7 +9,7 @@ rows = collections.defaultdict(list)          # (kernel, counter) -> [(grid, val
 for f in sorted(glob.glob(root + "/**/*_counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"]
-        if not (("k_render" in name or "k_stream" in name) and "true" not in name.split("(")[0]):
+        if not (("k_render" in name or "k_stream" in name or "k_sort" in name) and "true" not in name.split("(")[0]):
             continue
         short = re.sub(r"^void ", "", name.split("(")[0])
         rows[(short, r["Counter_Name"])].append((int(r.get("Grid_Size", 0) or 0), float(r["Counter_Value"])))

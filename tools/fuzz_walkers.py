@@ -1,0 +1,70 @@
+"""Differential fuzz of the four forms of the render path on the GPU (one-off, not part of the test suite): seeded random
+scenes (tests/random_scenes.py) and random 'triangle soup' scenes at random sizes, recursion depths, samples per pixel,
+row shards and -- for the wavefront form -- random queue budgets (several bands), compared BIT FOR BIT on the image and
+on every counter with the lane walker.  usage: fuzz_walkers.py [first seed] [number of seeds]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import numpy as np
+
+import yahr_amd
+from random_scenes import random_scene_desc
+from yahr_amd import scenes
+
+COUNT_KEYS = ("primary_rays", "reflection_rays", "shadow_rays", "shaded_hits", "box_tests", "tri_tests", "sphere_tests")
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+bad = 0
+ran = {}
+for seed in range(first, first + count):
+    rng = np.random.default_rng(50_000 + seed)
+    if seed % 3 == 2:
+        d = scenes.random_tris(int(rng.integers(50, 20000)), int(rng.integers(20, 200)), int(rng.integers(10, 120)),
+                               depth=int(rng.integers(1, 5)), bvh_depth=int(rng.integers(0, 21)), seed=int(rng.integers(1, 1 << 30)))
+    else:
+        d = random_scene_desc(seed)
+        d = d.with_camera(imW=int(rng.integers(9, 300)), imH=int(rng.integers(5, 160)))
+    scene = d.to_scene().build()
+    spp = int(rng.choice([1, 1, 2, 3, 4, 8, 16, 64]))
+    kw = dict(spp=spp, seed=int(rng.integers(0, 1000)))
+    if rng.random() < 0.3:
+        kw.update(n_shards=int(rng.integers(2, 5)), strip_rows=int(rng.integers(1, 12)))
+        kw["shard"] = int(rng.integers(0, kw["n_shards"]))
+    ref = None
+    for mode, name in ((yahr_amd.TRAVERSE_LANE, "lane"), (yahr_amd.TRAVERSE_PACKET, "packet"),
+                       (yahr_amd.TRAVERSE_HYBRID, "adaptive"), (yahr_amd.TRAVERSE_STREAM, "stream"),
+                       (yahr_amd.TRAVERSE_STREAM, "stream-bands")):
+        if name == "stream-bands":
+            tile_rows_bytes = max(1, scene.width * spp * (141 + 32 * max(1, d.depth)) * 8)
+            os.environ["YAHR_STREAM_BUDGET_KB"] = str(max(1, int(tile_rows_bytes * rng.uniform(1.0, 4.0)) >> 10))
+        try:
+            if "n_shards" in kw:
+                import torch
+                ctx = yahr_amd.Context(scene, 0)
+                t = ctx.render(traverse=mode, collect_stats=True, **kw)
+                torch.cuda.synchronize()
+                img, st = t.cpu().numpy(), ctx.stats()
+                ctx.close()
+            else:
+                img, st = yahr_amd.render_image(scene, traverse=mode, collect_stats=True, **kw)
+        except yahr_amd.YahrError as e:
+            if name == "stream-bands":              # budget below one tile row: an explicit STREAM request is an error
+                continue
+            raise
+        finally:
+            os.environ.pop("YAHR_STREAM_BUDGET_KB", None)
+        ran[name] = ran.get(name, 0) + 1
+        if ref is None:
+            ref = (img, st)
+            continue
+        same = np.array_equal(np.ascontiguousarray(img).view(np.uint32), np.ascontiguousarray(ref[0]).view(np.uint32))
+        cnt = [k for k in COUNT_KEYS if st[k] != ref[1][k]]
+        if not same or cnt:
+            bad += 1
+            print(f"MISMATCH seed {seed} {name} kw {kw} size {scene.width}x{scene.height} depth {d.depth}: image {'same' if same else 'DIFFERS'} counters {cnt}", flush=True)
+    if seed % 20 == 0:
+        print(f"seed {seed} ok so far (mismatches: {bad})", flush=True)
+print(f"done: {count} seeds, {bad} mismatches; renders per form: {ran}")
+sys.exit(1 if bad else 0)

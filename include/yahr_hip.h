@@ -169,7 +169,11 @@ enum {
   YAHR_TRAVERSE_HYBRID = 3,    /* adaptive: a packet while the rays stay coherent, then every lane on its own */
   YAHR_TRAVERSE_STREAM = 4     /* wavefront form: camera rays as packets, then ONE LAUNCH PER RECURSION LEVEL with the
                                   surviving paths compacted into a queue in HBM between launches (ballot + prefix),
-                                  so every wavefront of a level starts with 64 live rays; same image, same counters */
+                                  so every wavefront of a level starts with 64 live rays, and the level launches run in
+                                  Morton order of the hit points (counting sort on the device); same image, same
+                                  counters.  Needs 141 + 32 x depth bytes of device memory per sample of a band of
+                                  rows (allocated inside the context on first use; bands are sized to an eighth of
+                                  the free memory) */
 };
 enum {
   YAHR_TILES_WAVE = 0,         /* 8x8-pixel tile per wavefront */

@@ -122,6 +122,11 @@ int yahr_scene_parse(const char *text, size_t len, int lenient, yahr_host_scene 
 /* The loader's numeric-literal conversion on its own (tests): decimal / 0x / 0o lexeme -> binary32, correctly
  * rounded as GHC's `read :: Float` does (Scene.hs derives Read). */
 int yahr_parse_float32(const char *lexeme, size_t len, float *out);
+/* Texts of a megabyte and more are parsed by several threads (YAHR_PARSE_THREADS, default: the host's cores, at most
+ * 16): long lists are cut at their top-level commas and the runs parsed side by side; any error falls back to the
+ * sequential code, so results and error messages do not depend on the thread count.  Diagnostics (tests): how many
+ * lists of the calling thread's last yahr_scene_parse / yahr_scene_load went that way. */
+int32_t yahr_debug_parallel_lists(void);
 
 /* programmatic assembly: what a foreign host marshals instead of text */
 int yahr_scene_new(yahr_host_scene **out);

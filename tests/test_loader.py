@@ -240,3 +240,131 @@ def test_float_literals_round_trip_and_round_correctly():
     assert _parse_f32("0x1F") == np.float32(31) and _parse_f32("0o17") == np.float32(15)
     assert _parse_f32("1e-45") == np.float32(1e-45) and _parse_f32("1e39") == np.float32(np.inf)
     assert _parse_f32("0.000") == np.float32(0) and _parse_f32("000123.4500") == np.float32(123.45)
+
+
+# ---- long lists parsed by several threads (scene_parse.cpp: list_into / parallel_list / scan_list_parallel) ----------
+def _arrays_equal(a, b):
+    for k in a:
+        x, y = np.ascontiguousarray(a[k]), np.ascontiguousarray(b[k])
+        assert x.shape == y.shape and np.array_equal(x.view(np.uint8), y.view(np.uint8)), k
+
+
+def _parse_with(text, threads, monkeypatch, min_bytes="1"):
+    monkeypatch.setenv("YAHR_PARSE_THREADS", str(threads))
+    if threads > 1:
+        monkeypatch.setenv("YAHR_PARSE_PARALLEL_MIN", min_bytes)
+    else:
+        monkeypatch.delenv("YAHR_PARSE_PARALLEL_MIN", raising=False)
+    return yahr_amd.Scene.parse(text)
+
+
+def _parallel_lists():
+    return yahr_amd.lib.yahr_debug_parallel_lists()
+
+
+def _tricky_scene_text(rng, n_records=150):
+    """objects that exercise the bracket scan: material ids with brackets, commas, escaped quotes and backslashes,
+    redundant parentheses, a mesh between loose records, a nested Subsampled list"""
+    ids = ['m', 'a,b', ']', '[(', 'q\\"uote', 'back\\\\slash', 'end\\\\', '{x}', 'two\\\\\\\\', 'gap\\   \\ped']
+    names = ['m', 'a,b', ']', '[(', 'q"uote', 'back\\slash', 'end\\', '{x}', 'two\\\\', 'gapped']
+    mats = ", ".join('BlinnPhongMaterial { id = "%s", ambient = Vec3 0 0 0, diffuse = Vec3 %g 0.5 0.25, specular = Vec3 0 0 0, '
+                     'shininess = %d }' % (i, 0.1 + 0.05 * k, k + 1) for k, i in enumerate(ids))
+
+    def v3():
+        x = rng.uniform(-3, 3, 3)
+        return "Vec3 %s %s %s" % tuple(("(%r)" % float(np.float32(c))) if c < 0 or rng.random() < 0.2 else repr(float(np.float32(c))) for c in x)
+    objs = []
+    for k in range(n_records):
+        i = ids[int(rng.integers(len(ids)))]
+        r = rng.random()
+        if r < 0.55:
+            o = 'Triangle { p0 = %s, p1 = %s, p2 = %s, n0 = %s, n1 = %s, n2 = %s, materialId = "%s" }' % (v3(), v3(), v3(), v3(), v3(), v3(), i)
+        elif r < 0.8:
+            o = 'Sphere { position = (%s), radius = %r, materialId = ("%s") }' % (v3(), float(np.float32(rng.uniform(0.1, 1))), i)
+        elif r < 0.9:
+            nv = int(rng.integers(3, 40))
+            tris = ",".join("(%d, %d,%d)" % tuple(rng.integers(0, nv, 3)) for _ in range(int(rng.integers(1, 60))))
+            o = ('TriangleMesh { triangleMeshPoints = [%s], triangleMeshNormals = Nothing, triangleMeshTriangles = [%s], '
+                 'triangleMeshSmooth = Nothing, materialId = "%s" }' % (",".join(v3() for _ in range(nv)), tris, i))
+        else:
+            inner = ", ".join('Sphere { position = %s, radius = 0.25, materialId = "%s" }' % (v3(), i) for _ in range(int(rng.integers(1, 30))))
+            o = 'Subsampled { subsampleSize = 0.5, subsampledObjects = [%s] }' % inner
+        if rng.random() < 0.15:
+            o = "((%s))" % o
+        objs.append(o)
+    return MIN_SCENE % (mats, "PointLight (Vec3 0 5 0) (Vec3 50 50 50)", ",\n ".join(objs)), names
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_parallel_lists_give_the_sequential_scene(seed, monkeypatch):
+    rng = np.random.default_rng(4000 + seed)
+    text, _ = _tricky_scene_text(rng)
+    ref = _parse_with(text, 1, monkeypatch).build().arrays()
+    assert _parallel_lists() == 0
+    for threads in (2, 3, 5, 16):
+        sc = _parse_with(text, threads, monkeypatch)
+        assert _parallel_lists() >= 1                    # the objects list at least (150 elements >= 4 x threads)
+        _arrays_equal(ref, sc.build().arrays())
+    # one big mesh (lists of points, normals, index triples, smooth flags) and the bunny file
+    d = scenes.pseudo_bunny(32, 18, n_lon=40, n_lat=21)
+    ref = _parse_with(d.to_text(), 1, monkeypatch).build().arrays()
+    for threads in (2, 7):
+        sc = _parse_with(d.to_text(), threads, monkeypatch)
+        assert _parallel_lists() >= 3                    # points, normals, index triples (, smooth flags)
+        _arrays_equal(ref, sc.build().arrays())
+        # a threshold between the sizes of the lists: the long ones by threads, the short ones not
+        sc = _parse_with(d.to_text(), threads, monkeypatch, min_bytes="20000")
+        assert 1 <= _parallel_lists() <= 3
+        _arrays_equal(ref, sc.build().arrays())
+
+
+def test_parallel_lists_report_the_sequential_error(monkeypatch):
+    """whatever goes wrong inside a list parsed by threads, the error (message and byte offset) is the sequential
+    parser's: syntax errors in the middle and at the end of a long list, an unterminated string, unbalanced brackets,
+    a missing closing bracket, a string gap (which the chunked bracket scan refuses)"""
+    rng = np.random.default_rng(7)
+    good, _ = _tricky_scene_text(rng, 120)
+    at = good.index("objects = [") + len("objects = [")
+    mid = good.index("},", at + len(good[at:]) // 2) + 1
+    variants = [good[:mid] + ", Sphere { position = Vec3 0 0, radius = 1, materialId = \"m\" }" + good[mid:],   # too few components
+                good[:mid] + ", Cube { }" + good[mid:],
+                good[:mid] + ", " + good[mid:],                                                                   # empty element
+                good[:mid] + ")" + good[mid:],                                                                    # stray bracket
+                good[:mid] + ", Sphere { position = Vec3 0 0 1, radius = 1, materialId = \"m }" + good[mid:],     # unterminated string
+                good.rstrip()[:-3],                                                                                # no closing ] }
+                good[:mid] + " \\ " + good[mid:]]                                                                 # backslash outside a string
+    for text in variants:
+        with pytest.raises(yahr_amd.YahrError) as e1:
+            _parse_with(text, 1, monkeypatch)
+        for threads in (2, 5):
+            with pytest.raises(yahr_amd.YahrError) as e2:
+                _parse_with(text, threads, monkeypatch)
+            assert str(e2.value) == str(e1.value)
+
+
+def test_mesh_index_out_of_bounds_is_reported_for_the_first_offending_triangle():
+    """expand (Scene.hs:62-79) indexes the point and normal lists with `!!`: a bad index is an error at build time.
+    Big meshes are expanded by several threads; the message names what the FIRST bad triangle got wrong."""
+    def mesh(n_tris, bad):
+        tris = [(0, 1, 2)] * n_tris
+        smooth = ["False"] * n_tris
+        for k, what in bad:
+            if what == "points":
+                tris[k] = (0, 9, 2)
+            else:
+                tris[k] = (0, 1, 3); smooth[k] = "True"                # index 3: a point, but no normal
+        obj = ('TriangleMesh { triangleMeshPoints = [Vec3 0 0 0, Vec3 1 0 0, Vec3 0 1 0, Vec3 0 0 1], '
+               'triangleMeshNormals = Just [Vec3 0 0 1, Vec3 0 0 1, Vec3 0 0 1], triangleMeshTriangles = [%s], '
+               'triangleMeshSmooth = Just [%s], materialId = "m" }' % (",".join("(%d,%d,%d)" % t for t in tris), ",".join(smooth)))
+        return yahr_amd.Scene.parse(MIN_SCENE % (MAT, "", obj))
+    mesh(10, []).build()
+    for n in (10, 200_000):                                            # sequential and threaded expansion
+        for bad, word in (([(n - 1, "points")], "points"), ([(n // 2, "normals")], "normals"),
+                          ([(n // 3, "normals"), (n - 2, "points")], "normals"), ([(3, "points"), (n - 1, "normals")], "points")):
+            with pytest.raises(yahr_amd.YahrError) as e:
+                mesh(n, bad).build()
+            assert "out of bounds (%s)" % word in str(e.value), (n, bad)
+        # smooth = False: the normals are not looked at (lazy `if`, Scene.hs:70-78)
+        s = mesh(n, [])
+        s.build()
+        assert s.arrays()["prim_p0"].shape[0] == n

@@ -174,6 +174,30 @@ def test_png_ppm_pfm(tmp_path):
         yahr_amd.write_png("/nonexistent_dir/x.png", rgb)
 
 
+def test_png_deflated_in_bands_decodes_to_the_same_pixels(tmp_path, monkeypatch):
+    """images of 128 rows and more are deflated in bands by several threads into ONE zlib stream (sync flush between
+    the bands, combined Adler-32): whatever the number of bands, the file must decode to the same pixels -- with this
+    file's decoder (zlib.decompress checks the Adler-32 of the whole) and with PIL when it is there"""
+    rng = np.random.default_rng(5)
+    h, w = 333, 257
+    rgb = (rng.random((h, w, 3)) ** 3).astype(np.float32)
+    rgb[100:200] = np.linspace(0, 1, w, dtype=np.float32)[None, :, None]            # a compressible part too
+    want = np.floor(np.float32(255.0) * np.clip(rgb, np.float32(0), np.float32(1))).astype(np.uint8)   # binary32 product, as to_ldr
+    sizes = {}
+    for threads in (1, 2, 5, 16):
+        monkeypatch.setenv("YAHR_PNG_THREADS", str(threads))
+        p = str(tmp_path / ("o%d.png" % threads))
+        yahr_amd.write_png(p, rgb)
+        assert np.array_equal(decode_png(p), want), threads
+        sizes[threads] = os.path.getsize(p)
+        try:
+            from PIL import Image
+            assert np.array_equal(np.asarray(Image.open(p).convert("RGB")), want)
+        except ImportError:
+            pass
+    assert sizes[5] < 1.02 * sizes[1]                                               # the bands cost next to nothing in size
+
+
 # ---- command line (argument handling; the render itself needs a GPU: tests/test_gpu_cli.py) ----------
 YAHR = os.path.join(ROOT, "bin", "yahr")
 

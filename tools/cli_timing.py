@@ -9,13 +9,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT]
 from yahr_amd import scenes
 
-src = "/tmp/bunny.yahrr"
-open(src, "w").write(scenes.pseudo_bunny().to_text())
+big = len(sys.argv) > 1 and sys.argv[1] == "tris1m"       # the 152 MB scene of BASELINE config 5 instead of the bunny
+src = "/tmp/tris1m.yahrr" if big else "/tmp/bunny.yahrr"
+open(src, "w").write((scenes.random_tris(1_000_000, 1920, 1080, depth=2, bvh_depth=20) if big else scenes.pseudo_bunny()).to_text())
 print("scene file %.1f MB" % (os.path.getsize(src) / 1e6))
-for ext in ("png", "ppm", "pfm"):
+for ext, threads in (("png", None), ("ppm", None), ("pfm", None), ("ppm", "1")):
     for i in range(3):
         t = time.perf_counter()
-        r = subprocess.run([os.path.join(ROOT, "bin", "yahr"), src, "/tmp/o." + ext, "-p", "hip"], capture_output=True, text=True,
-                           env=dict(os.environ, YAHR_TIMING="1"))
+        env = dict(os.environ, YAHR_TIMING="1")
+        if threads:
+            env["YAHR_PARSE_THREADS"] = threads
+        r = subprocess.run([os.path.join(ROOT, "bin", "yahr"), src, "/tmp/o." + ext, "-p", "hip"], capture_output=True, text=True, env=env)
         dt = time.perf_counter() - t
-        print("%s run %d: %.3f s wall, rc %d | %s" % (ext, i, dt, r.returncode, " | ".join(r.stderr.strip().splitlines()[-2:])))
+        print("%s%s run %d: %.3f s wall, rc %d | %s" % (ext, " (1 parse thread)" if threads else "", i, dt, r.returncode,
+                                                      " | ".join(r.stderr.strip().splitlines()[-2:])))

@@ -102,6 +102,7 @@ SIGNATURES = {
     "yahr_device_count": (C.c_int, []),
     "yahr_device_mem_info": (C.c_int, [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "yahr_debug_fail_alloc": (None, [C.c_int32]),
+    "yahr_debug_parallel_lists": (C.c_int32, []),
     "yahr_ctx_create": (C.c_int, [C.POINTER(FlatScene), C.c_int, C.POINTER(_VP)]),
     "yahr_ctx_destroy": (None, [_VP]),
     "yahr_shard_rows": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),

@@ -9,6 +9,7 @@
 // and emits the tree in the reference's DFS order as a skip-linked node array (include/yahr_hip.h).
 #include "host_scene.hpp"
 
+#include <atomic>
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -236,23 +237,39 @@ void expand_object(const SceneObject &o, const std::function<int32_t(const std::
       size_t n = o.tris.size() / 3;
       if (o.has_smooth && o.smooth.size() < n) n = o.smooth.size();  // zipWith truncates
       int32_t mat = mat_of(o.material_id);
-      for (size_t k = 0; k < n; ++k) {
+      // every triangle on its own (big meshes on several threads); an index out of bounds is reported for the FIRST
+      // offending triangle, as a sequential walk would
+      const size_t base = out.size();
+      out.resize(base + n);
+      std::atomic<size_t> first_bad{n};
+      parallel_for(n, [&](size_t k) {
         int32_t i0 = o.tris[3 * k], i1 = o.tris[3 * k + 1], i2 = o.tris[3 * k + 2];
-        auto chk = [&](int32_t i, size_t lim, const char *what) {
-          if (i < 0 || (size_t)i >= lim) throw std::runtime_error(std::string("TriangleMesh index out of bounds (") + what + ")");
-        };
-        chk(i0, o.points.size(), "points"); chk(i1, o.points.size(), "points"); chk(i2, o.points.size(), "points");
+        auto ok = [&](int32_t i, size_t lim) { return i >= 0 && (size_t)i < lim; };
+        bool sm = o.has_smooth ? (o.smooth[k] != 0) : false;        // fromMaybe (repeat False)
+        const bool use_normals = o.has_normals && sm;
+        if (!(ok(i0, o.points.size()) && ok(i1, o.points.size()) && ok(i2, o.points.size())) ||
+            (use_normals && !(ok(i0, o.normals.size()) && ok(i1, o.normals.size()) && ok(i2, o.normals.size())))) {
+          size_t cur = first_bad.load();
+          while (k < cur && !first_bad.compare_exchange_weak(cur, k)) {}
+          return;
+        }
         Primitive t; t.kind = 0; t.mat = mat;
         t.p0 = o.points[i0]; t.p1 = o.points[i1]; t.p2 = o.points[i2];
-        bool sm = o.has_smooth ? (o.smooth[k] != 0) : false;        // fromMaybe (repeat False)
-        if (o.has_normals && sm) {
-          chk(i0, o.normals.size(), "normals"); chk(i1, o.normals.size(), "normals"); chk(i2, o.normals.size(), "normals");
+        if (use_normals) {
           t.n0 = o.normals[i0]; t.n1 = o.normals[i1]; t.n2 = o.normals[i2];
         } else {
           Vec3 nf = norm(cross(sub(t.p2, t.p0), sub(t.p1, t.p0)));   // :78
           t.n0 = nf; t.n1 = nf; t.n2 = nf;
         }
-        out.push_back(t);
+        out[base + k] = t;
+      });
+      if (first_bad.load() < n) {
+        const size_t k = first_bad.load();
+        const int32_t i0 = o.tris[3 * k], i1 = o.tris[3 * k + 1], i2 = o.tris[3 * k + 2];
+        auto ok = [&](int32_t i, size_t lim) { return i >= 0 && (size_t)i < lim; };
+        const bool pts = ok(i0, o.points.size()) && ok(i1, o.points.size()) && ok(i2, o.points.size());
+        out.resize(base);
+        throw std::runtime_error(std::string("TriangleMesh index out of bounds (") + (pts ? "normals" : "points") + ")");
       }
       break;
     }

@@ -74,6 +74,7 @@ struct HostScene {
 // parser: throws ParseError
 struct ParseError { std::string msg; size_t offset; };
 std::unique_ptr<HostScene> parse_scene(const char *text, size_t len, bool lenient);
+int parse_parallel_lists();      // lists of this thread's last parse_scene that were parsed by several threads
 // one numeric lexeme (decimal, hexadecimal, octal) -> binary32, correctly rounded like GHC's read (scene_parse.cpp)
 float parse_float_literal(const char *s, size_t len);
 

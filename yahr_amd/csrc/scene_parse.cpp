@@ -16,8 +16,13 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <array>
+#include <iterator>
 #include <functional>
 #include <limits>
+#include <thread>
+#include <vector>
 
 #include "host_scene.hpp"
 
@@ -78,6 +83,8 @@ float parse_float_literal(const char *s, size_t len) {
 
 namespace {
 
+thread_local int g_parallel_lists = 0;
+
 enum class Tok { End, Ident, Number, String, Punct };
 
 struct Token {
@@ -90,7 +97,7 @@ struct Token {
 
 class Parser {
  public:
-  Parser(const char *t, size_t n, bool lenient) : text_(t), n_(n), lenient_(lenient) {}
+  Parser(const char *t, size_t n, bool lenient, int threads = 1) : text_(t), n_(n), lenient_(lenient), threads_(threads) {}
 
   std::unique_ptr<HostScene> scene() {
     auto hs = std::make_unique<HostScene>();
@@ -101,7 +108,7 @@ class Parser {
       field("camera"); hs->camera = camera(0); expect(',');
       field("materials"); list([&] { hs->materials.push_back(material(0)); }); expect(',');
       field("lights"); list([&] { hs->lights.push_back(light(0)); }); expect(',');
-      field("objects"); list([&] { hs->objects.push_back(object(0)); });
+      field("objects"); list_into(hs->objects, [](Parser &p, std::vector<SceneObject> &o) { o.push_back(p.object(0)); });
       expect('}');
     });
     if (peek().kind != Tok::End) fail("trailing input after Scene");   // `read` requires a full parse
@@ -110,6 +117,7 @@ class Parser {
 
  private:
   const char *text_; size_t n_; bool lenient_;
+  int threads_ = 1;            // > 1: long lists are parsed by that many threads (list_into)
   size_t pos_ = 0;
   bool has_peek_ = false; Token peek_; size_t after_peek_ = 0;
 
@@ -247,6 +255,265 @@ class Parser {
       if (is_punct(']')) { next(); return; }
       while (true) {
         elem();
+        if (is_punct(',')) { next(); continue; }
+        expect(']'); break;
+      }
+    });
+  }
+
+  // ---- long lists in parallel --------------------------------------------------------------------------
+  // A scene of a million triangles is one list of a million records (or three lists of points, normals and index
+  // triples): 150 MB of text that a single thread reads at 170 MB/s.  list_into() parses such a list with several
+  // threads: ONE pass over its bytes finds the closing bracket and the commas between its elements (bracket depth,
+  // string literals skipped -- nothing else in this grammar can hide a bracket or a comma), the elements are dealt
+  // to the threads in contiguous runs of about equal size, every thread runs an ordinary Parser over its run, and
+  // the runs are appended in order.  Whatever goes wrong in there (a syntax error, brackets that do not balance)
+  // makes the list fall back to the sequential code, so the error reported -- message and offset -- is the
+  // sequential parser's.
+  static constexpr size_t kParallelMinBytes = (size_t)1 << 20;
+  static size_t parallel_min_bytes() {
+    const char *e = std::getenv("YAHR_PARSE_PARALLEL_MIN");          // tests: force the parallel path on small lists
+    return e ? (size_t)std::strtoull(e, nullptr, 10) : kParallelMinBytes;
+  }
+
+  // `from`: just behind the list's '[' or behind one of its commas.  Finds the list's ']' and the commas at its depth;
+  // false if the brackets do not balance
+  bool scan_list(size_t from, size_t &close, std::vector<size_t> &commas) const {
+    static const auto cls = [] {
+      std::array<uint8_t, 256> t{};
+      t[(unsigned char)'('] = t[(unsigned char)'['] = t[(unsigned char)'{'] = 1;
+      t[(unsigned char)')'] = t[(unsigned char)']'] = t[(unsigned char)'}'] = 2;
+      t[(unsigned char)','] = 3; t[(unsigned char)'"'] = 4;
+      return t;
+    }();
+    int depth = 1;
+    size_t p = from;
+    while (p < n_) {
+      const uint8_t k = cls[(unsigned char)text_[p]];
+      if (k == 0) { ++p; continue; }
+      if (k == 1) { ++depth; ++p; continue; }
+      if (k == 2) {
+        if (--depth == 0) { close = p; return text_[p] == ']'; }
+        ++p; continue;
+      }
+      if (k == 3) { if (depth == 1) commas.push_back(p); ++p; continue; }
+      // string literal, with lex()'s own rules: to the closing quote; a backslash takes the next character with it
+      // (\" and \\; the digits of a numeric escape are ordinary characters here), except that backslash + white
+      // space opens a string gap that runs to the next backslash
+      ++p;
+      while (p < n_ && text_[p] != '"') {
+        if (text_[p] != '\\') { ++p; continue; }
+        if (++p >= n_) return false;
+        const char e = text_[p];
+        if (e == ' ' || e == '\n' || e == '\t' || e == '\r') {
+          while (p < n_ && (text_[p] == ' ' || text_[p] == '\n' || text_[p] == '\t' || text_[p] == '\r')) ++p;
+          if (p >= n_ || text_[p] != '\\') return false;
+        }
+        ++p;
+      }
+      if (p >= n_) return false;
+      ++p;
+    }
+    return false;
+  }
+
+  // The same scan by several threads, for lists too long to walk twice with one: the text is cut into chunks (never
+  // right behind a backslash).  Pass 1 walks every chunk under both hypotheses -- it starts outside / inside a string
+  // literal -- and keeps the state it ends in, the net bracket depth and the lowest depth reached; chaining the chunks
+  // gives every chunk's true start state and depth and tells which chunk holds the closing bracket.  Pass 2 walks the
+  // chunks again with that knowledge and records the commas at depth 1.  Chunks are taken in waves of one per thread
+  // until the closing bracket is found, so the work follows the length of the list, not of the file.  A backslash
+  // followed by white space (a string gap: the one construct whose meaning depends on more than one preceding
+  // character) makes the whole thing return false; the caller then uses the sequential scan_list.
+  struct ChunkEnd { bool in_str; int delta, low; bool gap; };
+  // walks [b, e); depth counts from 0 at b; commas != nullptr: records commas at depth == want and stops at the
+  // bracket that takes the depth below `floor_depth` (returns its position in *stop)
+  ChunkEnd walk_chunk(size_t b, size_t e, bool in_str, std::vector<size_t> *commas, int want, int floor_depth, size_t *stop) const {
+    // per byte outside a string: a table lookup for the bracket depth and one rarely taken branch for comma, quote and backslash
+    static const auto tab = [] {
+      std::array<int8_t, 256> d{}; std::array<uint8_t, 256> sp{};
+      d[(unsigned char)'('] = d[(unsigned char)'['] = d[(unsigned char)'{'] = 1;
+      d[(unsigned char)')'] = d[(unsigned char)']'] = d[(unsigned char)'}'] = -1;
+      sp[(unsigned char)','] = sp[(unsigned char)'"'] = sp[(unsigned char)'\\'] = 1;
+      return std::make_pair(d, sp);
+    }();
+    const auto &delta = tab.first; const auto &special = tab.second;
+    ChunkEnd r{in_str, 0, 0, false};
+    size_t p = b;
+    int depth = 0;
+    while (p < e) {
+      if (r.in_str) {
+        const char c = text_[p];
+        if (c == '"') { r.in_str = false; ++p; continue; }
+        if (c == '\\') {
+          const char d = p + 1 < n_ ? text_[p + 1] : ' ';
+          if (d == ' ' || d == '\n' || d == '\t' || d == '\r') { r.gap = true; return r; }
+          p += 2; continue;                      // (never across e: no chunk starts right behind a backslash)
+        }
+        ++p; continue;
+      }
+      while (p < e) {
+        const unsigned char c = (unsigned char)text_[p];
+        depth += delta[c];
+        if (depth < r.low) {
+          r.low = depth;
+          if (commas && depth < floor_depth) { *stop = p; r.delta = depth; return r; }
+        }
+        if (special[c]) {
+          if (c == ',') { if (commas && depth == want) commas->push_back(p); }
+          else if (c == '"') { r.in_str = true; ++p; break; }
+          else { r.gap = true; return r; }      // a backslash outside a string: a lexical error, the sequential code reports it
+        }
+        ++p;
+      }
+    }
+    r.delta = depth;
+    return r;
+  }
+
+  enum class Scan { Done, TooFewElements, NeedSequential };
+  Scan scan_list_parallel(size_t from, size_t &close, std::vector<size_t> &commas) const {
+    const int T = threads_;
+    size_t at = from;                 // start of the next wave
+    bool in_str = false;              // state and depth (1 = inside the list) at `at`
+    int depth = 1;
+    std::vector<std::vector<size_t>> found;
+    size_t n_found = 0;
+    for (int wave = 0; at < n_; ++wave) {
+      const size_t chunk = (size_t)1 << (20 + std::min(wave, 3));     // 1, 2, 4, 8, 8, ... MiB: few thread starts
+      std::vector<size_t> cut(1, at);
+      for (int r = 0; r < T && cut.back() < n_; ++r) {
+        size_t b = std::min(n_, cut.back() + chunk);
+        while (b < n_ && text_[b - 1] == '\\') ++b;
+        cut.push_back(b);
+      }
+      const int C = (int)cut.size() - 1;
+      std::vector<ChunkEnd> out_h(C), in_h(C);
+      auto pass1 = [&](int r) {
+        out_h[r] = walk_chunk(cut[r], cut[r + 1], false, nullptr, 0, 0, nullptr);
+        // started inside a string: without a quote or a backslash in the chunk (the rule) it never leaves it
+        const char *c0 = text_ + cut[r]; const size_t len = cut[r + 1] - cut[r];
+        if (!std::memchr(c0, '"', len) && !std::memchr(c0, '\\', len)) in_h[r] = ChunkEnd{true, 0, 0, false};
+        else in_h[r] = walk_chunk(cut[r], cut[r + 1], true, nullptr, 0, 0, nullptr);
+      };
+      {
+        std::vector<std::thread> pool;
+        for (int r = 1; r < C; ++r) pool.emplace_back(pass1, r);
+        pass1(0);
+        for (auto &t : pool) t.join();
+      }
+      // chain: start state / depth of every chunk, and the first chunk in which the depth reaches 0
+      std::vector<char> s_in(C); std::vector<int> s_depth(C);
+      int closing = -1;
+      for (int r = 0; r < C; ++r) {
+        s_in[r] = in_str; s_depth[r] = depth;
+        const ChunkEnd &h = in_str ? in_h[r] : out_h[r];
+        if (h.gap) return Scan::NeedSequential;
+        if (depth + h.low <= 0) { closing = r; break; }
+        in_str = h.in_str; depth += h.delta;
+      }
+      const int last = closing >= 0 ? closing : C - 1;
+      std::vector<std::vector<size_t>> part(last + 1);
+      std::vector<size_t> stop(last + 1, (size_t)-1);
+      auto pass2 = [&](int r) {
+        // depth counts from 0 inside walk_chunk: the list's own depth is 1 - s_depth[r] there
+        walk_chunk(cut[r], cut[r + 1], s_in[r] != 0, &part[r], 1 - s_depth[r], 1 - s_depth[r], &stop[r]);
+      };
+      {
+        std::vector<std::thread> pool;
+        for (int r = 1; r <= last; ++r) pool.emplace_back(pass2, r);
+        pass2(0);
+        for (auto &t : pool) t.join();
+      }
+      for (int r = 0; r <= last; ++r) { n_found += part[r].size(); found.push_back(std::move(part[r])); }
+      if (closing >= 0) {
+        if (stop[closing] == (size_t)-1 || text_[stop[closing]] != ']') return Scan::NeedSequential;
+        close = stop[closing];
+        commas.reserve(n_found);
+        for (auto &v : found) commas.insert(commas.end(), v.begin(), v.end());
+        return Scan::Done;
+      }
+      // elements of several MiB each: the long lists are inside them, and those get their own threads
+      if (n_found < (size_t)(wave + 1) * (size_t)T / 4) return Scan::TooFewElements;
+      at = cut[C];
+    }
+    return Scan::NeedSequential;
+  }
+
+  // Out: a std::vector; elem(Parser &, Out &) parses one element and appends what it yields
+  template <class Out, class F> bool parallel_list(size_t from, Out &out, F elem, size_t per_elem) {
+    size_t close = 0;
+    std::vector<size_t> commas;
+    const Scan sc = scan_list_parallel(from, close, commas);
+    if (sc == Scan::TooFewElements) return false;
+    if (sc == Scan::NeedSequential) {
+      commas.clear();
+      if (!scan_list(from, close, commas)) return false;
+    }
+    if (close - from < parallel_min_bytes() || commas.size() + 1 < (size_t)threads_ * 4) return false;
+    const size_t n_elem = commas.size() + 1;
+    const int T = threads_;
+    // run r = elements [first[r], first[r + 1]): cut at the comma nearest to r/T of the bytes
+    std::vector<size_t> first(T + 1, 0);
+    first[T] = n_elem;
+    for (int r = 1; r < T; ++r) {
+      const size_t target = from + (close - from) / (size_t)T * (size_t)r;
+      const size_t k = (size_t)(std::lower_bound(commas.begin(), commas.end(), target) - commas.begin());
+      first[r] = std::max(first[r - 1], std::min(k + 1, n_elem));
+    }
+    std::vector<Out> parts(T);
+    std::vector<char> ok(T, 1);
+    auto work = [&](int r) {
+      const size_t e0 = first[r], e1 = first[r + 1];
+      if (e0 >= e1) return;
+      const size_t begin = e0 == 0 ? from : commas[e0 - 1] + 1;
+      const size_t end = e1 == n_elem ? close : commas[e1 - 1];
+      try {
+        Parser sub(text_, end, lenient_, 1);
+        sub.pos_ = begin;
+        Out mine;                                        // (not parts[r] directly: the vector headers share cache lines)
+        mine.reserve((e1 - e0) * per_elem);
+        for (size_t e = e0; e < e1; ++e) {
+          elem(sub, mine);
+          if (e + 1 < e1) sub.expect(',');
+        }
+        if (sub.peek().kind != Tok::End) ok[r] = 0;
+        parts[r] = std::move(mine);
+      } catch (const ParseError &) {
+        ok[r] = 0;
+      } catch (...) {
+        ok[r] = 0;
+      }
+    };
+    std::vector<std::thread> pool;
+    for (int r = 1; r < T; ++r) pool.emplace_back(work, r);
+    work(0);
+    for (auto &t : pool) t.join();
+    for (int r = 0; r < T; ++r) if (!ok[r]) return false;
+    size_t total = out.size();
+    for (int r = 0; r < T; ++r) total += parts[r].size();
+    out.reserve(total);
+    for (int r = 0; r < T; ++r) out.insert(out.end(), std::make_move_iterator(parts[r].begin()), std::make_move_iterator(parts[r].end()));
+    pos_ = close + 1; has_peek_ = false;
+    ++g_parallel_lists;
+    return true;
+  }
+
+  template <class Out, class F> void list_into(Out &out, F elem, size_t per_elem = 1) {     // GHC.Read.list, elements at precedence 0;
+                                                                                              // per_elem: entries of `out` per element
+    parens(0, 11, [&] {
+      expect('[');
+      if (is_punct(']')) { next(); return; }
+      bool try_threads = threads_ > 1;
+      while (true) {
+        const size_t e0 = peek().pos;
+        if (try_threads) {                             // the rest of the list, from this element on, by several threads?
+          try_threads = false;
+          if (n_ - e0 >= parallel_min_bytes() && parallel_list(e0, out, elem, per_elem)) return;
+        }
+        elem(*this, out);
+        // after an element of megabytes (a mesh) a long run of small ones may still follow: look again
+        if (threads_ > 1 && pos_ - e0 >= parallel_min_bytes()) try_threads = true;
         if (is_punct(',')) { next(); continue; }
         expect(']'); break;
       }
@@ -431,16 +698,16 @@ class Parser {
         expect('}');
       } else if (is_ident("TriangleMesh")) {
         next(); expect('{'); o.kind = SceneObject::TriangleMesh;
-        field("triangleMeshPoints"); list([&] { o.points.push_back(vec3(0)); }); expect(',');
+        field("triangleMeshPoints"); list_into(o.points, [](Parser &p, std::vector<Vec3> &v) { v.push_back(p.vec3(0)); }); expect(',');
         if (!lenient_ || is_ident("triangleMeshNormals")) {
           field("triangleMeshNormals");
-          maybe([&] { o.has_normals = true; parens(11, 11, [&] { list([&] { o.normals.push_back(vec3(0)); }); }); });
+          maybe([&] { o.has_normals = true; parens(11, 11, [&] { list_into(o.normals, [](Parser &p, std::vector<Vec3> &v) { v.push_back(p.vec3(0)); }); }); });
           expect(',');
         }
-        field("triangleMeshTriangles"); list([&] { tri_tuple(o.tris); }); expect(',');
+        field("triangleMeshTriangles"); list_into(o.tris, [](Parser &p, std::vector<int32_t> &v) { p.tri_tuple(v); }, 3); expect(',');
         if (!lenient_ || is_ident("triangleMeshSmooth")) {
           field("triangleMeshSmooth");
-          maybe([&] { o.has_smooth = true; parens(11, 11, [&] { list([&] { o.smooth.push_back(boolean() ? 1 : 0); }); }); });
+          maybe([&] { o.has_smooth = true; parens(11, 11, [&] { list_into(o.smooth, [](Parser &p, std::vector<uint8_t> &v) { v.push_back(p.boolean() ? 1 : 0); }); }); });
           expect(',');
         }
         field("materialId"); o.material_id = string_lit();
@@ -448,7 +715,7 @@ class Parser {
       } else if (is_ident("Subsampled")) {
         next(); expect('{'); o.kind = SceneObject::Subsampled;
         field("subsampleSize"); o.subsample_size = number_f(); expect(',');
-        field("subsampledObjects"); list([&] { o.children.push_back(object(0)); });
+        field("subsampledObjects"); list_into(o.children, [](Parser &p, std::vector<SceneObject> &c) { c.push_back(p.object(0)); });
         expect('}');
       } else {
         fail("expected Sphere, Triangle, TriangleMesh or Subsampled");
@@ -460,8 +727,18 @@ class Parser {
 
 }  // namespace
 
+int parse_parallel_lists() { return g_parallel_lists; }
+
 std::unique_ptr<HostScene> parse_scene(const char *text, size_t len, bool lenient) {
-  Parser p(text, len, lenient);
+  int threads = 1;
+  if (len >= ((size_t)1 << 20) || std::getenv("YAHR_PARSE_PARALLEL_MIN")) {
+    const char *e = std::getenv("YAHR_PARSE_THREADS");
+    threads = e ? std::atoi(e) : (int)std::thread::hardware_concurrency();
+    if (threads > 16) threads = 16;
+    if (threads < 1) threads = 1;
+  }
+  g_parallel_lists = 0;
+  Parser p(text, len, lenient, threads);
   return p.scene();
 }
 

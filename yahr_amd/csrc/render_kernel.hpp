@@ -74,7 +74,9 @@ struct SParams {
   unsigned *hist;                          // [depth + 1][YD_SORT_CELLS] entries per cell of queue k; zeroed by the caller with the queue lengths
   unsigned *start;                         // [YD_SORT_CELLS] first slot of a cell (exclusive scan of hist[k])
 };
+#ifndef YD_SORT_BITS
 #define YD_SORT_BITS 18                    // 6 bits per axis: 64^3 cells of the root box
+#endif
 #define YD_SORT_CELLS (1u << YD_SORT_BITS)
 
 enum { TRAV_LANE = 1, TRAV_PACKET = 2, TRAV_ADAPTIVE = 3, TRAV_STREAM = 4 };

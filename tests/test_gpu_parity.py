@@ -637,6 +637,41 @@ def test_extreme_operands_walkers_agree(gpu, bvh_depth):
     ctx.close()
 
 
+def test_extreme_scene_renders_the_same_in_all_forms(gpu):
+    """A scene whose root box is astronomically large or not finite (vertices at 1e38, subnormal and degenerate
+    triangles): hit points then fall outside any sensible Morton cell, or their cell coordinate is NaN or infinite
+    -- the wavefront form's counting sort must put them SOMEWHERE (cell 0 or the last one) and the image, NaN pixels
+    included, and every counter must stay bit-identical to the other forms."""
+    rng = np.random.default_rng(99)
+    mags = np.array([0.0, 1e-45, 1e-38, 1e-20, 1.0, 1.0, 3.0, 1e3, 1e20, 1e38], dtype=np.float64)
+
+    def extreme(shape):
+        return (rng.choice(mags, size=shape) * rng.choice([-1.0, 1.0], size=shape) * rng.uniform(0.5, 1.0, size=shape)).astype(np.float32)
+    objs = []
+    for i in range(120):
+        if i % 3 == 0:
+            p = [extreme(3) for _ in range(3)]
+        else:
+            c = rng.uniform(-2, 2, 3) + (0, 0, 6)
+            p = [c + rng.uniform(-1.5, 1.5, 3) for _ in range(3)]
+        p = [tuple(np.asarray(v, dtype=np.float32).tolist()) for v in p]
+        nrm = np.cross(np.subtract(p[2], p[0], dtype=np.float64), np.subtract(p[1], p[0], dtype=np.float64))
+        with np.errstate(all="ignore"):
+            nrm = tuple(np.nan_to_num(nrm / (np.linalg.norm(nrm) + 1e-300), posinf=1.0, neginf=-1.0).astype(np.float32).tolist())
+        objs.append(("triangle", p[0], p[1], p[2], nrm, nrm, nrm, "sphere"))
+    for bvh_depth in (0, 5, 16):
+        d = scenes.scene_fixed(72, 40).with_(objects=objs, bvh_depth=bvh_depth, depth=3)
+        scene = d.to_scene().build()
+        for spp in (1, 16):
+            ref, st0 = yahr_amd.render_image(scene, spp=spp, seed=4, traverse=yahr_amd.TRAVERSE_LANE, collect_stats=True)
+            assert st0["shaded_hits"] > 100                                 # not vacuous
+            for m in (yahr_amd.TRAVERSE_PACKET, yahr_amd.TRAVERSE_HYBRID, yahr_amd.TRAVERSE_STREAM):
+                img, st1 = yahr_amd.render_image(scene, spp=spp, seed=4, traverse=m, collect_stats=True)
+                assert np.array_equal(bits(img), bits(ref)), (bvh_depth, spp, m)
+                for k in COUNT_KEYS:
+                    assert st0[k] == st1[k], (k, bvh_depth, spp, m)
+
+
 @pytest.mark.parametrize("mode", [yahr_amd.TRAVERSE_AUTO, yahr_amd.TRAVERSE_STREAM])
 def test_render_can_be_captured_in_a_hip_graph(gpu, mode):
     """yahr_ctx_render is asynchronous on the caller's stream and allocation-free after the first use of a

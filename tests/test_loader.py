@@ -370,14 +370,14 @@ def test_mesh_index_out_of_bounds_is_reported_for_the_first_offending_triangle()
         assert s.arrays()["prim_p0"].shape[0] == n
 
 
-def test_default_settings_parse_the_bunny_file_by_threads():
+def test_default_settings_parse_the_bunny_file_by_threads(monkeypatch):
     """no environment knobs: the 4.8 MB pseudo-bunny text is above the megabyte threshold, so its point, normal and
     index lists go to the threaded path with the host's core count -- and must give the scene of the programmatic path"""
     d = scenes.pseudo_bunny()
     text = d.to_text()
     assert len(text) > (1 << 20)
     for k in ("YAHR_PARSE_THREADS", "YAHR_PARSE_PARALLEL_MIN"):
-        assert k not in os.environ
+        monkeypatch.delenv(k, raising=False)
     sc = yahr_amd.Scene.parse(text)
     if (os.cpu_count() or 1) > 1:
         assert _parallel_lists() >= 2

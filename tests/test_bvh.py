@@ -117,3 +117,11 @@ def test_concurrent_subtree_build_is_the_same_tree(split, monkeypatch):
     assert sorted(seq) == sorted(par)
     for k in seq:
         assert np.ascontiguousarray(seq[k]).tobytes() == np.ascontiguousarray(par[k]).tobytes(), k
+    # the passes over a big node's items (centroid bounds, SAH buckets, stable partition) in chunks on several threads:
+    # forced down to nodes of 64 items, with 2 to 16 threads per node
+    monkeypatch.setenv("YAHR_BUILD_CHUNK_MIN", "64")
+    for p in ("1", "2", "4"):
+        monkeypatch.setenv("YAHR_BUILD_PAR", p)
+        chunked = d.to_scene().build().arrays()
+        for k in seq:
+            assert np.ascontiguousarray(seq[k]).tobytes() == np.ascontiguousarray(chunked[k]).tobytes(), (k, p)

@@ -72,6 +72,14 @@ template <class F> void parallel_for(size_t n, F fn) {
   for (auto &x : th) x.join();
 }
 
+// fn(t) for t = 0 .. T-1, each on a thread of its own (the caller's thread takes t = 0)
+template <class F> void run_threads(int T, F fn) {
+  std::vector<std::thread> th;
+  for (int t = 1; t < T; ++t) th.emplace_back([=] { fn(t); });
+  fn(0);
+  for (auto &x : th) x.join();
+}
+
 // ---- BVH builder -------------------------------------------------------------------------------
 struct Builder {
   // the permutation being partitioned carries each primitive's centroid with it: bounds and partitions then
@@ -83,11 +91,27 @@ struct Builder {
   std::vector<yahr_node> &nodes;
   int split_mode;
 
+  // The passes over a big node's items (bounds of the centroids, SAH buckets, the stable partition) are cut into
+  // contiguous chunks for several threads when NO centroid is a NaN: the reference's folds use Haskell's min/max, whose
+  // results depend on the order of the operands only through NaNs and through which of two equal values (+0, -0) wins
+  // -- the first for min, the last for max -- and combining the chunks' results in chunk order keeps exactly that.  A
+  // NaN centroid (a NaN or an empty box) sends the whole build down the sequential passes.
+  bool clean = true;
+  int32_t chunked_min = 131072;          // items from which a pass is chunked (YAHR_BUILD_CHUNK_MIN: tests)
+
   Builder(const std::vector<Box> &b, std::vector<yahr_node> &n, int split) : boxes(b), nodes(n), split_mode(split) {
     order.resize(b.size());
-    for (size_t i = 0; i < b.size(); ++i) order[i] = Item{box_centroid(b[i]), (int32_t)i};
+    std::atomic<bool> nan_seen{false};
+    parallel_for(b.size(), [&](size_t i) {
+      const Vec3 c = box_centroid(b[i]);
+      order[i] = Item{c, (int32_t)i};
+      if (c.x != c.x || c.y != c.y || c.z != c.z) nan_seen.store(true, std::memory_order_relaxed);
+    });
+    clean = !nan_seen.load();
     scratch.resize(b.size());
+    if (const char *e = std::getenv("YAHR_BUILD_CHUNK_MIN")) chunked_min = (int32_t)std::max(2, std::atoi(e));
   }
+  bool chunked(int32_t n, int threads) const { return threads > 1 && clean && n >= chunked_min && n >= 2 * threads; }
 
   static void put(yahr_node &nd, Box bb, int32_t a, int32_t b) {
     nd.lo[0] = bb.lo.x; nd.lo[1] = bb.lo.y; nd.lo[2] = bb.lo.z; nd.a = a;
@@ -105,7 +129,31 @@ struct Builder {
   }
 
   // stable partition of order[first, first+n) by pred; returns size of the left part
-  template <class P> int32_t stable_split(int32_t first, int32_t n, P pred) {
+  template <class P> int32_t stable_split(int32_t first, int32_t n, P pred, int threads = 1) {
+    if (chunked(n, threads)) {
+      // count per chunk, then every chunk writes its left and right items to their final places in `scratch`
+      const int T = threads;
+      std::vector<int32_t> left((size_t)T + 1, 0);
+      auto lo_of = [&](int t) { return (int32_t)((int64_t)n * t / T); };
+      run_threads(T, [&](int t) {
+        int32_t c = 0;
+        for (int32_t i = lo_of(t), e = lo_of(t + 1); i < e; ++i) c += pred(order[first + i]) ? 1 : 0;
+        left[(size_t)t + 1] = c;
+      });
+      for (int t = 0; t < T; ++t) left[(size_t)t + 1] += left[(size_t)t];          // left items in front of chunk t
+      const int32_t nl_all = left[(size_t)T];
+      run_threads(T, [&](int t) {
+        int32_t l = left[(size_t)t], r = nl_all + (lo_of(t) - left[(size_t)t]);
+        for (int32_t i = lo_of(t), e = lo_of(t + 1); i < e; ++i) {
+          const Item p = order[first + i];
+          if (pred(p)) scratch[first + l++] = p; else scratch[first + r++] = p;
+        }
+      });
+      run_threads(T, [&](int t) {
+        std::copy(scratch.begin() + first + lo_of(t), scratch.begin() + first + lo_of(t + 1), order.begin() + first + lo_of(t));
+      });
+      return nl_all;
+    }
     int32_t nl = 0, nr = 0;
     for (int32_t i = 0; i < n; ++i) {
       const Item p = order[first + i];
@@ -127,17 +175,34 @@ struct Builder {
     return (int)fl;
   }
 
-  int32_t midpoint(int32_t first, int32_t n, int d, Box cb) {       // Culling.hs:56-60
+  int32_t midpoint(int32_t first, int32_t n, int d, Box cb, int threads = 1) {       // Culling.hs:56-60
     float mid = dim(d, box_centroid(cb));
-    return stable_split(first, n, [&](const Item &p) { return dim(d, p.c) <= mid; });
+    return stable_split(first, n, [&](const Item &p) { return dim(d, p.c) <= mid; }, threads);
   }
 
-  int32_t sah(int32_t first, int32_t n, int d, Box cb) {            // Culling.hs:62-112
-    if (!(n > 4)) return midpoint(first, n, d, cb);
+  int32_t sah(int32_t first, int32_t n, int d, Box cb, int threads = 1) {            // Culling.hs:62-112
+    if (!(n > 4)) return midpoint(first, n, d, cb, threads);
     constexpr int NB = 16;
     float cmin = dim(d, cb.lo), cmax = dim(d, cb.hi);
     int cnt[NB]; Box bbs[NB];
     for (int i = 0; i < NB; ++i) { cnt[i] = 0; bbs[i] = box_empty(); }
+    if (chunked(n, threads)) {
+      // buckets per chunk, joined in chunk order (see `clean`)
+      const int T = threads;
+      struct Part { int cnt[NB]; Box bbs[NB]; };
+      std::vector<Part> part((size_t)T);
+      run_threads(T, [&](int t) {
+        Part &q = part[(size_t)t];
+        for (int i = 0; i < NB; ++i) { q.cnt[i] = 0; q.bbs[i] = box_empty(); }
+        for (int32_t i = (int32_t)((int64_t)n * t / T), e = (int32_t)((int64_t)n * (t + 1) / T); i < e; ++i) {
+          const Item &p = order[first + i];
+          int b = bucket_id(p, d, cmin, cmax);
+          q.cnt[b] += 1; q.bbs[b] = box_join(q.bbs[b], boxes[p.id]);
+        }
+      });
+      for (int t = 0; t < T; ++t)
+        for (int i = 0; i < NB; ++i) { cnt[i] += part[(size_t)t].cnt[i]; bbs[i] = box_join(bbs[i], part[(size_t)t].bbs[i]); }
+    } else
     for (int32_t i = 0; i < n; ++i) {
       const Item &p = order[first + i];
       int b = bucket_id(p, d, cmin, cmax);
@@ -155,7 +220,7 @@ struct Builder {
       if (i == 0) { best_i = 0; best_c = cost; }
       else if (!(best_c < cost) && !(best_c == cost)) { best_i = i; best_c = cost; }
     }
-    return stable_split(first, n, [&](const Item &p) { return bucket_id(p, d, cmin, cmax) <= best_i; });
+    return stable_split(first, n, [&](const Item &p) { return bucket_id(p, d, cmin, cmax) <= best_i; }, threads);
   }
 
   // buildTree (Culling.hs:31-50); emits the subtree's nodes in DFS order at the end of `out` and returns its box.
@@ -173,11 +238,28 @@ struct Builder {
       return bb;
     }
     if (max_depth == 0) return emit_multi_leaf(out, first, n);       // :34
+    // the passes over this node's items run on 2^par threads (16 at the root, 8 in each of its children, ...: the
+    // subtrees of a level are built concurrently, below)
+    const int threads = par > 0 ? std::min(1 << std::min(par, 4), (int)std::max(1u, std::thread::hardware_concurrency())) : 1;
     // bbOfCentroids = boundAllPoints (map centroid bbs)  (:49, AABBs.hs:20-23)
-    Box cb = box_from_points(order[first].c, order[first + 1].c);
-    for (int32_t i = 2; i < n; ++i) cb = box_include(cb, order[first + i].c);
+    Box cb;
+    if (chunked(n, threads)) {
+      const int T = threads;
+      std::vector<Box> part((size_t)T);
+      run_threads(T, [&](int t) {
+        const int32_t b = (int32_t)((int64_t)n * t / T), e = (int32_t)((int64_t)n * (t + 1) / T);
+        Box q; q.lo = order[first + b].c; q.hi = order[first + b].c;  // = box_from_points with the element after it
+        for (int32_t i = b + 1; i < e; ++i) q = box_include(q, order[first + i].c);
+        part[(size_t)t] = q;
+      });
+      cb = part[0];
+      for (int t = 1; t < T; ++t) cb = box_join(cb, part[(size_t)t]);
+    } else {
+      cb = box_from_points(order[first].c, order[first + 1].c);
+      for (int32_t i = 2; i < n; ++i) cb = box_include(cb, order[first + i].c);
+    }
     int d = max_dimension(sub(cb.hi, cb.lo));                        // :48
-    int32_t nl = (split_mode == YAHR_SPLIT_SAH) ? sah(first, n, d, cb) : midpoint(first, n, d, cb);
+    int32_t nl = (split_mode == YAHR_SPLIT_SAH) ? sah(first, n, d, cb, threads) : midpoint(first, n, d, cb, threads);
     if (nl == n) return emit_multi_leaf(out, first, n);              // :36-37  null xs2
     size_t me = out.size();
     out.push_back(yahr_node{});

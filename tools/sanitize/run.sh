@@ -14,7 +14,7 @@ txt, _ = T._tricky_scene_text(np.random.default_rng(3), 4000)
 open(w + "/tricky.yahrr", "w").write(txt)
 open(w + "/bad.yahrr", "w").write(txt[: len(txt) // 2] + ") " + txt[len(txt) // 2:])
 PY
-export YAHR_PARSE_PARALLEL_MIN=1 YAHR_PARSE_THREADS=6 YAHR_PNG_THREADS=5
+export YAHR_PARSE_PARALLEL_MIN=1 YAHR_PARSE_THREADS=6 YAHR_PNG_THREADS=5 YAHR_BUILD_CHUNK_MIN=64
 for san in address,undefined thread; do
   g++ -std=c++17 -O1 -g -fsanitize=$san -I$ROOT/include -I$SRC $ROOT/tools/sanitize/host_harness.cpp $SRC/scene_parse.cpp $SRC/host_scene.cpp $SRC/abi_host.cpp -lz -lpthread -o $W/h
   echo "== -fsanitize=$san"; (cd $W && ./h mesh.yahrr tricky.yahrr bad.yahrr)

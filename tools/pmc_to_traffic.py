@@ -18,6 +18,7 @@ depth = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 def per_frame(counter):
     if depth:                                   # wavefront form
         return (vals["k_stream_primary"].get(counter, 0.0) + vals["k_stream_resolve"].get(counter, 0.0)
+                + vals["k_stream_resolve_lanes"].get(counter, 0.0)        # (one of the two resolve kernels runs, by spp)
                 + depth * (vals["k_stream_level"].get(counter, 0.0) + vals["k_sort_scan"].get(counter, 0.0)
                            + vals["k_sort_scatter"].get(counter, 0.0)))
     return vals["k_render"].get(counter, 0.0) / F

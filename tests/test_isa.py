@@ -105,3 +105,37 @@ def test_register_budget_and_no_scratch(asm):
         m = meta(asm, k)
         assert m["vgpr_count"] <= 64, m
         assert m["vgpr_spill_count"] <= 56, m
+
+
+# the wavefront form: k_stream_primary<STATS>, k_stream_level<MODE, STATS>, the counting sort and the resolve kernels
+STREAM_PRIMARY = "_Z16k_stream_primaryILb0EE"
+STREAM_LEVEL = "_Z14k_stream_levelILi3ELb0EE"
+
+
+def whole_body(asm, prefix):
+    """like kernel_body, but to the end of the function: these kernels leave early (s_endpgm) when their wavefront lies
+    beyond the queue's length"""
+    m = re.search(r"^%s\w*:[^\n]*\n(.*?)^\.Lfunc_end" % re.escape(prefix), asm, flags=re.S | re.M)
+    assert m, prefix
+    return m.group(1)
+
+
+def test_wavefront_form_kernels(asm):
+    # camera rays: the packet walker with its scalar record loads, although the kernel ends in queue appends
+    # (atomics and stores -- they all come after the last traversal, so the loads keep their scalar path)
+    body = whole_body(asm, STREAM_PRIMARY)
+    assert len(re.findall(r"s_load_dwordx8", body)) >= 5
+    m = meta(asm, STREAM_PRIMARY)
+    assert m["vgpr_count"] <= 72 and m["vgpr_spill_count"] <= 8, m
+    # level launches: adaptive walker (packet start with scalar loads, then per-lane gathers), all 8 wave slots
+    body = whole_body(asm, STREAM_LEVEL)
+    assert len(re.findall(r"s_load_dwordx8", body)) >= 5 and len(re.findall(r"global_load_dword", body)) >= 20
+    m = meta(asm, STREAM_LEVEL)
+    assert m["vgpr_count"] <= 64 and m["vgpr_spill_count"] <= 24, m
+    for k in (STREAM_PRIMARY, STREAM_LEVEL):
+        b = whole_body(asm, k)
+        assert "v_mad_f32" not in b and "v_mac_f32" not in b and "v_pk_fma_f32" not in b
+    # the small kernels between them: nothing spilled
+    for k in ("_Z11k_sort_scan", "_Z14k_sort_scatter", "_Z22k_stream_resolve_lanes", "_Z16k_stream_resolve7RParams"):
+        m = meta(asm, k)
+        assert m["vgpr_spill_count"] == 0 and m["private_segment_fixed_size"] == 0, (k, m)

@@ -25,22 +25,22 @@ Midpoint.
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field's definition).
 """
 import argparse
+import hashlib
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [ROOT]
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
-import yahr_amd
-from yahr_amd import scenes
-from yahr_amd.dist import ShardPipeline, ShardPlan
+# torch, numpy and yahr_amd are imported in main() only: with --gpus N > 1 and no WORLD_SIZE in the environment this
+# process is a LAUNCHER -- it starts N ranks as a child `python -m torch.distributed.run` and must not touch the GPU
+# (nor pay for the imports) itself.
+np = torch = dist = yahr_amd = scenes = ShardPipeline = ShardPlan = None
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling ~6290 GB/s
 # vector-instruction issue ceiling of the chip from the microarch guide: 256 CUs x 4 SIMD-32, a wave64 VALU
@@ -48,6 +48,17 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); m
 VALU_PEAK_GINST_S = 1228.8
 
 # workload -> (scene description, text, point the camera orbit turns around)
+def _import_runtime():
+    global np, torch, dist, yahr_amd, scenes, ShardPipeline, ShardPlan
+    import numpy as np_
+    import torch as torch_
+    import torch.distributed as dist_
+    import yahr_amd as yahr_amd_
+    from yahr_amd import scenes as scenes_
+    from yahr_amd.dist import ShardPipeline as SP, ShardPlan as SPl
+    np, torch, dist, yahr_amd, scenes, ShardPipeline, ShardPlan = np_, torch_, dist_, yahr_amd_, scenes_, SP, SPl
+
+
 WORKLOADS = {
     "bunny": lambda: (scenes.pseudo_bunny(1920, 1080, depth=2),
                       "pseudo-bunny (procedural stand-in, 69,696 tris + 2-tri plane), 1920x1080, 1 spp, "
@@ -143,6 +154,39 @@ def load_profile(workload):
     return None
 
 
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a torch.distributed environment: start the N ranks ourselves, as a CHILD
+    process (never an exec, and before anything here touches the GPU), relay rank 0's JSON line and leave with the
+    child's status.  Same command shape as the driver's own multi-rank launch."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["YAHR_BENCH_SPAWNED"] = "1"
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in proc.stdout:                       # stderr passes straight through
+        if out.startswith('{"metric"'):
+            line = out.strip()
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        sys.stderr.write("bench.py: the ranks finished without printing a result line\n")
+        rc = 1
+    sys.exit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -154,22 +198,23 @@ def main():
     ap.add_argument("--frames-per-launch", type=int, default=8, help="per rank; a launch holds this x ranks frames")
     ap.add_argument("--repeats", type=int, default=0, help="repeats of the K-step block inside the timed region; 0 = "
                                                            "as many as make the region last --min-seconds")
-    ap.add_argument("--min-seconds", type=float, default=1.0)
+    ap.add_argument("--min-seconds", type=float, default=3.0)
     ap.add_argument("--same-camera", action="store_true", help="every frame of a batch uses the scene camera (diagnostics)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true",
                     help="finish gather + assembly of a launch before the next render starts (diagnostics)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args.gpus, sys.argv[1:])                 # does not return
+    _import_runtime()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if "YAHR_BENCH_FORCE_DEVICE" in os.environ:       # rehearsal of N ranks on one GPU (diagnostics only)
         local_rank = int(os.environ["YAHR_BENCH_FORCE_DEVICE"])
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+        args.gpus = world                                     # the launcher's world size is what runs
     assert torch.cuda.is_available(), "bench.py needs a GPU: yahr_amd has no CPU path"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -242,12 +287,14 @@ def main():
     st_tail = counted(f_tail) if f_tail else None
 
     def ray_counts(st):
-        t = torch.tensor([st["primary_rays"], st["reflection_rays"], st["shadow_rays"]], dtype=torch.int64, device=dev)
+        t = torch.tensor([st["primary_rays"], st["reflection_rays"], st["shadow_rays"], st["box_tests"],
+                          st["wave_node_steps"], st["tri_tests"] + st["sphere_tests"], st["wave_prim_steps"]],
+                         dtype=torch.int64, device=dev)
         if world > 1:
             dist.all_reduce(t)
-        return int(t.sum().item()), int(t[0].item())
-    rays_full, prim_full = ray_counts(st_full)
-    rays_tail, prim_tail = ray_counts(st_tail) if st_tail else (0, 0)
+        return int(t[:3].sum().item()), int(t[0].item()), [int(v) for v in t[3:].tolist()]
+    rays_full, prim_full, steps_full = ray_counts(st_full)
+    rays_tail, prim_tail, _ = ray_counts(st_tail) if st_tail else (0, 0, None)
     rays_per_block = n_full * rays_full + rays_tail
     prim_per_block = n_full * prim_full + prim_tail
 
@@ -288,6 +335,14 @@ def main():
     elapsed = float(el.item())
     kern_ms = [a.elapsed_time(b) for a, b in timed_ev]
     kernel_ms_avg = sum(kern_ms) / len(kern_ms) if kern_ms else float("nan")
+    # what every rank saw: its device, the world size of its process group, its own launch time
+    mine = torch.tensor([float(local_rank), float(dist.get_world_size() if world > 1 else 1), kernel_ms_avg,
+                         float(yahr_amd.shard_rows(h, world, rank, args.strip_rows))], dtype=torch.float64, device=dev)
+    table = torch.zeros((world, mine.numel()), dtype=torch.float64, device=dev)
+    table[rank] = mine
+    if world > 1:
+        dist.all_reduce(table)                 # (a sum of one-hot rows: all_reduce is what every backend offers)
+    per_rank = [[float(x) for x in row] for row in table.tolist()]
 
     # ---- a lone frame per launch (the scene camera): bound by its longest wave, reported beside the batch figure
     o_one = yahr_amd.make_opts(frames=1, **shard)
@@ -307,34 +362,54 @@ def main():
         checksum = float(img[0].double().sum().item())
         n_steps = R * K
         my_px = yahr_amd.shard_rows(h, world, rank, args.strip_rows) * w
-        alg = algorithmic_bytes(st_full, scene.n_lights, F * my_px)      # of this rank's F-frame launch
-        prof = load_profile(args.workload) if world == 1 else None
-        roof = {"kernel": (prof or {}).get("kernels", "k_render"), "kernel_ms_avg": round(kernel_ms_avg, 4),
-                "frames_per_launch": F, "launches_timed": len(kern_ms)}
-        if prof is not None and kern_ms:
+        alg = algorithmic_bytes(st_full, scene.n_lights, F * my_px)      # of rank 0's F-frame launch
+        prof = load_profile(args.workload)
+        from yahr_amd.srchash import kernel_source_hash
+        src_hash = kernel_source_hash()
+        matches = bool(prof is not None and prof.get("kernel_source_sha256") == src_hash)
+        # a launch ends when its slowest rank does; instruction counts add up over the ranks exactly, because a strip of
+        # 8 rows is one row of 8x8 wave tiles: the N ranks together run the very wavefronts of the one-rank launch
+        kernel_ms_job = max(r[2] for r in per_rank)
+        roof = {"kernel": (prof or {}).get("kernels", "k_render"), "kernel_ms_avg": round(kernel_ms_job, 4),
+                "frames_per_launch": F, "launches_timed": len(kern_ms),
+                "kernel_source_sha256": src_hash[:16], "profile_matches_source": matches,
+                "per_rank": [{"rank": i, "device": int(r[0]), "world_size_seen": int(r[1]), "rows": int(r[3]),
+                              "kernel_ms_avg": round(r[2], 4)} for i, r in enumerate(per_rank)]}
+        node_steps, node_lanes, prim_lanes, prim_steps = steps_full[1], steps_full[0], steps_full[2], steps_full[3]
+        # lanes that were logically at work per wavefront step (counted launch of the same batch): an issue fraction
+        # says the VALU is busy, this says how much of what it issues is useful
+        roof["lane_utilisation"] = {
+            "node_steps": round(node_lanes / (64.0 * node_steps), 4) if node_steps else None,
+            "primitive_steps": round(prim_lanes / (64.0 * prim_steps), 4) if prim_steps else None,
+            "source": "box tests / (64 x wavefront node steps), primitive tests / (64 x wavefront primitive steps) of the "
+                      "counted launch; wavefront steps are counted by the packet walker only"}
+        if prof is not None and kern_ms and matches:
             # what the counters say bounds the kernel: vector-instruction issue.  Instruction
             # counts are deterministic per frame, so the profile's per-frame figures (mean over the cameras of the
-            # orbit) scale to any number of frames per launch.
+            # orbit) scale to any number of frames per launch and add up over row shards.
             valu = int(prof["valu_insts_per_frame"] * F)
-            g = valu / (kernel_ms_avg * 1e-3) / 1e9
+            g = valu / (kernel_ms_job * 1e-3) / 1e9
             traffic = int(prof["hbm_bytes_per_frame"] * F)
+            peak = VALU_PEAK_GINST_S * world
             roof.update({
-                "bound": "valu-issue", "achieved": round(g, 1), "peak": VALU_PEAK_GINST_S, "unit": "G wave-instr/s",
-                "frac": round(g / VALU_PEAK_GINST_S, 4),
-                "peak_source": "MI355X_MICROARCH.md: 1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 VALU instruction",
-                "frac_of_measured_issue_peak": round(g / prof["valu_issue_peak_measured_ginst_s"], 4),
-                "measured_issue_peak": prof["valu_issue_peak_measured_ginst_s"],
+                "bound": "valu-issue", "achieved": round(g, 1), "peak": peak, "unit": "G wave-instr/s",
+                "frac": round(g / peak, 4),
+                "peak_source": "MI355X_MICROARCH.md: 1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 VALU instruction, x ranks",
+                "frac_of_measured_issue_peak": round(g / (prof["valu_issue_peak_measured_ginst_s"] * world), 4),
+                "measured_issue_peak": prof["valu_issue_peak_measured_ginst_s"] * world,
                 "valu_insts_per_launch": valu,
                 "traffic": traffic,
-                "hbm": {"achieved": round(traffic / (kernel_ms_avg * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(traffic / (kernel_ms_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "hbm": {"achieved": round(traffic / (kernel_ms_job * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                        "frac": round(traffic / (kernel_ms_job * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), 4),
                         "source": "rocprofv3 FETCH_SIZE (x2, gfx950) + WRITE_SIZE per frame x frames per launch"},
                 "profile": prof.get("source", "profiles/traffic_latest.json"),
             })
         else:
-            roof.update({"bound": "valu-issue", "achieved": None, "peak": VALU_PEAK_GINST_S, "unit": "G wave-instr/s",
+            roof.update({"bound": "valu-issue", "achieved": None, "peak": VALU_PEAK_GINST_S * world, "unit": "G wave-instr/s",
                          "frac": None, "traffic": None,
-                         "note": "no committed PMC profile for this workload / rank count (profiles/traffic_latest.json)"})
+                         "note": ("the committed PMC profile was taken from other kernel sources (kernel_source_sha256 differs): "
+                                  "re-run tools/profile_bench.sh + tools/pmc_to_traffic.py" if prof is not None and not matches
+                                  else "no committed PMC profile for this workload (profiles/traffic_<workload>.json)")})
         # SURVEY 8(d)'s algorithmic-byte model, kept as a FIELD: the records are served by scalar broadcasts and L2,
         # so this is not HBM traffic and is not a fraction of anything
         roof["algorithmic_bytes_per_launch"] = alg
@@ -345,7 +420,7 @@ def main():
             "value": round(rays_per_block * R / elapsed / 1e6, 2),
             "unit": "Mrays/s",
             "mpixels_per_s": round(prim_per_block / spp * R / elapsed / 1e6, 2),
-            "n_gpus": world, "steps": K, "warmup": args.warmup, "repeats": R, "frames_timed": n_steps,
+            "n_gpus": world, "world_size": int(per_rank[0][1]), "steps": K, "warmup": args.warmup, "repeats": R, "frames_timed": n_steps,
             "timed_region_s": round(elapsed, 4),
             "ms_per_step": round(elapsed / n_steps * 1e3, 4),
             "single_frame_ms": round(single_ms, 4),

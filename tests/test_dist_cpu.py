@@ -128,3 +128,43 @@ def test_pipeline_single_rank():
         pipe.submit(lambda s, n, st, out, i=i: out.fill_(float(i)))
     img = pipe.drain()
     assert img.shape == (2, 11, 4, 3) and float(img.min()) == 2.0 == float(img.max())
+
+
+def test_bench_starts_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` (the driver's command shape) must launch N ranks itself: a child
+    `python -m torch.distributed.run`, started before anything touches the GPU, rank 0's JSON line relayed and the
+    child's exit status passed on."""
+    import importlib
+    import io
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    assert bench.torch is None and bench.yahr_amd is None          # nothing heavy imported by the launcher
+    seen = {}
+
+    class FakeProc:
+        def __init__(self, cmd, env=None, stdout=None, text=None):
+            seen["cmd"], seen["env"] = cmd, env
+            self.stdout = io.StringIO('noise\n{"metric": "x", "n_gpus": 4}\n')
+
+        def wait(self):
+            return seen.get("rc", 0)
+
+    monkeypatch.setattr(bench.subprocess, "Popen", FakeProc)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "20", "--warmup", "5"])
+    out = io.StringIO()
+    monkeypatch.setattr(sys, "stdout", out)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "127.0.0.1" in cmd
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "20", "--warmup", "5"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert out.getvalue().strip() == '{"metric": "x", "n_gpus": 4}'
+    seen["rc"] = 3                                                  # a failing child fails the launcher
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 3

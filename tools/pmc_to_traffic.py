@@ -5,7 +5,9 @@ so bench.py scales them by its frames per launch.
   wavefront form: per frame one k_stream_primary, `depth` x (k_sort_scan, k_sort_scatter, k_stream_level) and one
   k_stream_resolve launch                       -> per frame = primary + depth x (scan + scatter + level) + resolve
 usage: pmc_to_traffic.py <pmc_summary.txt> <workload> <frames per launch> <source text> [stream depth] > profiles/traffic_<workload>.json"""
-import collections, json, re, sys
+import collections, json, os, re, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "yahr_amd"))
+from srchash import kernel_source_hash        # (the module alone: no GPU library is loaded for this)
 vals = collections.defaultdict(dict)          # kernel -> counter -> mean per dispatch (largest grid)
 for line in open(sys.argv[1]):
     m = re.match(r"^(k_\S.*?)\s{2,}(\S+)\s+grid=\s*(\d+)\s+n=.*mean=\s*([0-9.eE+-]+)", line)
@@ -27,6 +29,9 @@ def per_frame(counter):
 fetch_kb, write_kb = per_frame("FETCH_SIZE"), per_frame("WRITE_SIZE")
 out = {
     "workload": workload, "frames_per_launch_profiled": F, "source": source,
+    # fingerprint of the kernel sources + compiler flags the profile was taken from: bench.py quotes a roofline fraction
+    # only while it still matches (the profile must be converted in the same tree state it was measured in)
+    "kernel_source_sha256": kernel_source_hash(),
     "kernels": ("k_stream_primary + %d x (k_sort_scan + k_sort_scatter + k_stream_level) + k_stream_resolve per frame" % depth) if depth else "k_render, %d frames per launch" % F,
     "valu_insts_per_frame": per_frame("SQ_INSTS_VALU"),
     "salu_insts_per_frame": per_frame("SQ_INSTS_SALU"),

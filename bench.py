@@ -193,7 +193,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="bunny", choices=sorted(WORKLOADS))
-    ap.add_argument("--traverse", default="auto", choices=["auto", "lane", "packet", "hybrid", "stream"])
+    ap.add_argument("--traverse", default="auto", choices=["auto", "lane", "packet", "hybrid", "stream", "stack", "hybrid_stack", "ordered"])
     ap.add_argument("--strip-rows", type=int, default=8)
     ap.add_argument("--frames-per-launch", type=int, default=8, help="per rank; a launch holds this x ranks frames")
     ap.add_argument("--repeats", type=int, default=0, help="repeats of the K-step block inside the timed region; 0 = "
@@ -236,7 +236,8 @@ def main():
     w, h = scene.width, scene.height
     K = args.steps
     trav = {"auto": yahr_amd.TRAVERSE_AUTO, "lane": yahr_amd.TRAVERSE_LANE, "packet": yahr_amd.TRAVERSE_PACKET,
-            "hybrid": yahr_amd.TRAVERSE_HYBRID, "stream": yahr_amd.TRAVERSE_STREAM}[args.traverse]
+            "hybrid": yahr_amd.TRAVERSE_HYBRID, "stream": yahr_amd.TRAVERSE_STREAM, "stack": yahr_amd.TRAVERSE_STACK,
+            "hybrid_stack": yahr_amd.TRAVERSE_HYBRID_STACK, "ordered": yahr_amd.TRAVERSE_ORDERED}[args.traverse]
     # frames per launch: 8 per rank (every rank then gets as many tiles per launch as in the 1-GPU case, so the
     # per-launch tail stays amortised and the gathers get larger and fewer), never more than K
     F = max(1, min(args.frames_per_launch * world, K))
@@ -333,6 +334,8 @@ def main():
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
+    # (taken now: the lone-frame launches below reuse the first slot's buffer, which `img` may be a view of)
+    checksum = float(img[0].double().sum().item()) if rank == 0 else 0.0
     kern_ms = [a.elapsed_time(b) for a, b in timed_ev]
     kernel_ms_avg = sum(kern_ms) / len(kern_ms) if kern_ms else float("nan")
     # what every rank saw: its device, the world size of its process group, its own launch time
@@ -359,7 +362,6 @@ def main():
 
     if rank == 0:
         assert img is not None and tuple(img.shape) == (F, h, w, 3)
-        checksum = float(img[0].double().sum().item())
         n_steps = R * K
         my_px = yahr_amd.shard_rows(h, world, rank, args.strip_rows) * w
         alg = algorithmic_bytes(st_full, scene.n_lights, F * my_px)      # of rank 0's F-frame launch

@@ -172,13 +172,21 @@ enum {
   YAHR_TRAVERSE_LANE = 1,      /* every lane walks the node array on its own (vector loads) */
   YAHR_TRAVERSE_PACKET = 2,    /* the wavefront walks the union of its lanes' paths (scalar node loads) */
   YAHR_TRAVERSE_HYBRID = 3,    /* adaptive: a packet while the rays stay coherent, then every lane on its own */
-  YAHR_TRAVERSE_STREAM = 4     /* wavefront form: camera rays as packets, then ONE LAUNCH PER RECURSION LEVEL with the
+  YAHR_TRAVERSE_STREAM = 4,    /* wavefront form: camera rays as packets, then ONE LAUNCH PER RECURSION LEVEL with the
                                   surviving paths compacted into a queue in HBM between launches (ballot + prefix),
                                   so every wavefront of a level starts with 64 live rays, and the level launches run in
                                   Morton order of the hit points (counting sort on the device); same image, same
                                   counters.  Needs 141 + 32 x depth bytes of device memory per sample of a band of
                                   rows (allocated inside the context on first use; bands are sized to an eighth of
                                   the free memory) */
+  YAHR_TRAVERSE_STACK = 5,     /* STREAM whose secondary rays run on the stack walker: every lane on its own over child-PAIR
+                                  records (one fetch = both children's boxes) with an LDS stack of pending right siblings;
+                                  the reference's tests in the reference's order (same image, same counters) */
+  YAHR_TRAVERSE_HYBRID_STACK = 6, /* STREAM, secondary rays: a packet while coherent, then the stack walker */
+  YAHR_TRAVERSE_ORDERED = 7    /* OPT-IN, not the reference's order: STREAM whose secondary rays visit the NEARER child
+                                  first (stack walker); an exact tie in t still goes to the primitive that is later in
+                                  the reference's order.  Same closest hit unless a hit lies in front of its own box's
+                                  computed entry distance (rounding); test COUNTS differ by design */
 };
 enum {
   YAHR_TILES_WAVE = 0,         /* 8x8-pixel tile per wavefront */
@@ -207,7 +215,9 @@ typedef struct yahr_render_opts {
    * yahr_ctx_set_cameras (the scene camera when none were set).  0 and 1 mean a single frame. */
   int32_t frames;
   int32_t frame_rows;          /* rows between consecutive frames in d_rgb; 0 = packed (the rows rendered) */
-  int32_t reserved[4];
+  int32_t stream_walker;       /* diagnostics: walker of the stream form's secondary rays (YAHR_TRAVERSE_LANE / _PACKET /
+                                  _HYBRID / _STACK / _HYBRID_STACK / _ORDERED); 0 = the context's choice */
+  int32_t reserved[3];
 } yahr_render_opts;
 
 #define YAHR_TUNE_XCD_BANDS 1

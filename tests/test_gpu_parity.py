@@ -25,7 +25,11 @@ pytestmark = pytest.mark.gpu
 REL_TOL, ABS_TOL = 1e-4, 1e-6
 FUSED_MODES = [yahr_amd.TRAVERSE_LANE, yahr_amd.TRAVERSE_PACKET, yahr_amd.TRAVERSE_HYBRID]
 # ... plus the wavefront form (one launch per recursion level, paths compacted in between): same image, same counters
-MODES = FUSED_MODES + [yahr_amd.TRAVERSE_STREAM]
+# ... and the wavefront form with its secondary rays on the stack walkers (child-pair records + LDS stack of pending right
+# siblings): still the reference's tests in the reference's order -- same image, same counters
+STACK_MODES = [yahr_amd.TRAVERSE_STACK, yahr_amd.TRAVERSE_HYBRID_STACK]
+MODES = FUSED_MODES + [yahr_amd.TRAVERSE_STREAM] + STACK_MODES
+TRACE_MODES = [yahr_amd.TRAVERSE_LANE, yahr_amd.TRAVERSE_PACKET, yahr_amd.TRAVERSE_HYBRID] + STACK_MODES
 HERE = os.path.dirname(os.path.abspath(__file__))
 KAT = json.load(open(os.path.join(HERE, "golden", "spec_kat.json")))
 NTHREADS = min(16, os.cpu_count() or 4)
@@ -263,7 +267,7 @@ def test_kat_bvh_on_device(gpu, split):
     ctx = yahr_amd.Context(d.to_scene().build(), 0)
     rays = [[x, y, 0, 0, 0, 1, 1e6] for x, y in k["rays_xy"]]
     want = [((i - 1) * 10 + (j - 1)) * 2 + (kk - 1) for i, j, kk in k["expect_ijk"]]
-    for mode in (yahr_amd.TRAVERSE_LANE, yahr_amd.TRAVERSE_PACKET):
+    for mode in TRACE_MODES + [yahr_amd.TRAVERSE_ORDERED]:
         prim, _ = ctx.trace(rays, mode)
         assert list(prim) == want
     # random rays: identical closest hit and t as the oracle, both walkers
@@ -277,11 +281,12 @@ def test_kat_bvh_on_device(gpu, split):
     rr = np.concatenate([org, dr.astype(np.float32), np.full((n, 1), 1e6, np.float32)], axis=1)
     osc = OracleScene.from_desc(d).build()
     exp = [osc.intersect(r) for r in rr]
-    for mode in (yahr_amd.TRAVERSE_LANE, yahr_amd.TRAVERSE_PACKET):
+    for mode in TRACE_MODES + [yahr_amd.TRAVERSE_ORDERED]:
         prim, tt = ctx.trace(rr, mode)
-        assert list(prim) == [e[0] for e in exp]
+        assert list(prim) == [e[0] for e in exp], mode
         hit = prim >= 0
         assert np.array_equal(bits(tt[hit]), bits(np.array([e[1] for e in exp], dtype=np.float32)[hit]))
+        assert list(ctx.occluded(rr, mode)) == [int(e[0] >= 0) for e in exp]
     ctx.close()
 
 
@@ -627,6 +632,11 @@ def test_extreme_operands_walkers_agree(gpu, bvh_depth):
     assert np.array_equal(pl, pp)
     assert np.array_equal(tl.view(np.uint32), tp.view(np.uint32))
     assert np.array_equal(ctx.occluded(rays, yahr_amd.TRAVERSE_LANE), ctx.occluded(rays, yahr_amd.TRAVERSE_PACKET))
+    for mode in [yahr_amd.TRAVERSE_HYBRID] + STACK_MODES:       # (wavefronts with unsafe lanes fall back to the node array)
+        with np.errstate(all="ignore"):
+            ps, ts = ctx.trace(rays, mode)
+        assert np.array_equal(pl, ps) and np.array_equal(tl.view(np.uint32), ts.view(np.uint32)), mode
+        assert np.array_equal(ctx.occluded(rays, yahr_amd.TRAVERSE_LANE), ctx.occluded(rays, mode)), mode
     assert (pl >= 0).sum() > 50                                 # the test is not vacuous
     osc = OracleScene.from_desc(d).build()
     for i in range(0, n_rays, 7):
@@ -749,13 +759,13 @@ def test_error_paths_do_not_leak_device_memory(gpu):
     ctx.close()
     free0 = free_now()
     try:
-        for nth in range(1, 8):                                         # nodes, prims, normals, mats, lights, counters, cold
+        for nth in range(1, 9):                                         # nodes, prims, normals, mats, lights, counters, cold, pairs
             L.yahr_debug_fail_alloc(nth)
             with pytest.raises(yahr_amd.YahrError) as e:
                 yahr_amd.Context(scene, 0)
             assert e.value.code == -5, (nth, str(e.value))
             assert abs(free_now() - free0) <= slack, nth
-        L.yahr_debug_fail_alloc(8)                                      # beyond the last allocation: create succeeds
+        L.yahr_debug_fail_alloc(9)                                      # beyond the last allocation: create succeeds
         ctx = yahr_amd.Context(scene, 0)
         L.yahr_debug_fail_alloc(0)
         free1 = free_now()
@@ -767,7 +777,7 @@ def test_error_paths_do_not_leak_device_memory(gpu):
                     fn(arg)
                 assert e.value.code == -5
                 assert abs(free_now() - free1) <= slack, (fn.__name__, nth)
-        L.yahr_debug_fail_alloc(8)                                      # one-shot render: its image buffer (8th) fails
+        L.yahr_debug_fail_alloc(9)                                      # one-shot render: its image buffer (9th) fails
         with pytest.raises(yahr_amd.YahrError):
             yahr_amd.render_image(scene)
         assert abs(free_now() - free1) <= slack
@@ -838,3 +848,81 @@ def test_stream_form_in_row_bands(gpu, monkeypatch):
     monkeypatch.setenv("YAHR_STREAM_BUDGET_KB", "1")                     # not even one tile row: explicit STREAM is an error,
     with pytest.raises(yahr_amd.YahrError):                               # AUTO would fall back to the fused kernel
         yahr_amd.render_image(scene, traverse=yahr_amd.TRAVERSE_STREAM)
+
+
+# ---- stack walkers (child-pair records + LDS stack of pending right siblings) ---------------------------------------
+@pytest.mark.parametrize("bvh_depth,split", [(20, "Midpoint"), (6, "Midpoint"), (16, "SurfaceAreaHeuristic"), (1, "Midpoint")])
+def test_stack_walkers_on_incoherent_rays(gpu, bvh_depth, split):
+    """Random rays from inside a triangle soup (what a reflection ray looks like), closest and first hit: the stack
+    walkers must return the lane walker's primitive and t bit for bit -- they run the same tests in the same order --
+    and so must the opt-in ordered walker on this scene (its only licence to differ is a hit in front of its own box's
+    computed entry).  Also axis-aligned quads on an integer grid: exact ties in t between coplanar
+    triangles, which every walker must give to the primitive that is later in the reference's order."""
+    rng = np.random.default_rng(11 + bvh_depth)
+    d = scenes.random_tris(30000, 16, 16, bvh_depth=bvh_depth, seed=99).with_(split=split)
+    quads = []
+    for i in range(40):                                  # stacked, overlapping quads in the planes z = 2, 3, 4 (twice each)
+        z = float(2 + i % 3)
+        x, y = float(rng.integers(-6, 5)), float(rng.integers(-6, 5))
+        for rep in range(2):
+            quads.append(("triangle", (x, y, z), (x + 3, y, z), (x, y + 3, z), (0, 0, -1), (0, 0, -1), (0, 0, -1), "tri"))
+            quads.append(("triangle", (x + 3, y + 3, z), (x, y + 3, z), (x + 3, y, z), (0, 0, -1), (0, 0, -1), (0, 0, -1), "tri"))
+    d = d.with_(objects=d.objects + quads)
+    ctx = yahr_amd.Context(d.to_scene().build(), 0)
+    n = 64 * 96
+    org = rng.uniform(-9, 9, (n, 3)).astype(np.float32)
+    dirs = rng.normal(size=(n, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    org[: n // 4, 0:2] = rng.integers(-12, 12, (n // 4, 2)) * 0.5        # towards the quads, on grid lines too
+    org[: n // 4, 2] = -1.0
+    dirs[: n // 4] = (0, 0, 1)
+    tmax = np.where(rng.random(n) < 0.3, rng.uniform(0.5, 8.0, n), 1e6).astype(np.float32)
+    rays = np.concatenate([org, dirs, tmax[:, None]], axis=1).astype(np.float32)
+    pl, tl = ctx.trace(rays, yahr_amd.TRAVERSE_LANE)
+    ol = ctx.occluded(rays, yahr_amd.TRAVERSE_LANE)
+    assert (pl >= 0).mean() > 0.15
+    for mode in [yahr_amd.TRAVERSE_PACKET, yahr_amd.TRAVERSE_HYBRID] + STACK_MODES + [yahr_amd.TRAVERSE_ORDERED]:
+        ps, ts = ctx.trace(rays, mode)
+        if mode == yahr_amd.TRAVERSE_ORDERED:
+            # The flat quads are the documented exception: the box of an axis-aligned quad has no thickness, its computed
+            # entry distance can lie an ulp BEHIND the hit, and then the visit order decides which of two exactly
+            # coincident triangles is still reachable once the other has cut the ray.  Same t, possibly its twin.
+            twin = pl != ps
+            assert (pl[twin] >= 30000).all() and (ps[twin] >= 30000).all()        # only ever among the quads
+            print("ordered walker: %d of %d rays pick the coincident twin" % (int(twin.sum()), n))
+        else:
+            assert np.array_equal(pl, ps), (mode, int((pl != ps).sum()))
+        assert np.array_equal(bits(tl), bits(ts)), mode
+        assert np.array_equal(ol, ctx.occluded(rays, mode)), mode
+    osc = OracleScene.from_desc(d).build()
+    for i in range(0, n, 41):
+        w, t = osc.intersect(rays[i])
+        assert w == pl[i] and (w < 0 or np.float32(t).view(np.uint32) == tl[i].view(np.uint32)), i
+    ctx.close()
+
+
+def test_scene_without_pair_records_still_runs_the_stack_modes(gpu, monkeypatch):
+    """a tree whose root is a leaf (BVH 0), or pair records switched off: the stack modes fall back to the node array"""
+    d = scenes.pseudo_bunny(64, 36, n_lon=24, n_lat=13, bvh_depth=0)
+    assert_parity(d, modes=[yahr_amd.TRAVERSE_LANE] + STACK_MODES)
+    monkeypatch.setenv("YAHR_NO_PAIRS", "1")
+    assert_parity(scenes.scene_fixed(96, 64), modes=[yahr_amd.TRAVERSE_LANE] + STACK_MODES)
+
+
+def test_ordered_traversal_is_pixel_identical_here(gpu, tris1m):
+    """OPT-IN near-first traversal of the secondary rays (YAHR_TRAVERSE_ORDERED): not the reference's visit order, so
+    test COUNTS differ by design and are not compared; the closest hit is the reference's -- minimum t, an exact tie to
+    the primitive later in the reference's order -- unless a hit lies in front of its own box's computed entry.  Judged
+    on pixels: config 5's parameters at 120x68x16 spp and a random scene, against the oracle, with the number of
+    differing pixels reported (0 on these scenes)."""
+    for d, spp in ((tris1m.with_camera(imW=120, imH=68), 16), (random_scene_desc(3), 1), (scenes.pseudo_bunny(160, 90, depth=3), 1)):
+        ref, ost = oracle_render(d, spp, 0)
+        img, st = gpu_render(d, traverse=yahr_amd.TRAVERSE_ORDERED, spp=spp, seed=0)
+        base, bst = gpu_render(d, traverse=yahr_amd.TRAVERSE_STREAM, spp=spp, seed=0)
+        bad = outside_tol(img, ref)
+        differ = int((bits(img) != bits(base)).any(axis=2).sum())
+        print(f"ordered traversal: {bad} pixels outside tolerance, {differ} not bit-identical to the reference-order render; "
+              f"box tests {st['box_tests']} vs {bst['box_tests']} in reference order")
+        assert bad == 0 and differ == 0
+        for k in ("primary_rays", "reflection_rays", "shadow_rays", "shaded_hits"):
+            assert st[k] == ost[k], k

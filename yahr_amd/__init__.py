@@ -17,13 +17,13 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import (GATHER_AUTO, GATHER_NONE, GATHER_PEER, GATHER_RCCL, SPLIT_MIDPOINT, SPLIT_SAH, TILES_REFERENCE, TILES_WAVE, TRAVERSE_AUTO, TRAVERSE_HYBRID, TRAVERSE_STREAM,
+from ._lib import (GATHER_AUTO, GATHER_NONE, GATHER_PEER, GATHER_RCCL, SPLIT_MIDPOINT, SPLIT_SAH, TILES_REFERENCE, TILES_WAVE, TRAVERSE_AUTO, TRAVERSE_HYBRID, TRAVERSE_STREAM, TRAVERSE_STACK, TRAVERSE_HYBRID_STACK, TRAVERSE_ORDERED,
                    TRAVERSE_LANE, TRAVERSE_PACKET, TUNE_CENTRE_FIRST, TUNE_ONE_PIXEL_PER_LANE, TUNE_REGROUP, TUNE_XCD_BANDS, RenderOpts, Stats,
                    YahrError, check, lib)
 
 __all__ = ["Scene", "Context", "MultiContext", "GATHER_AUTO", "GATHER_RCCL", "GATHER_PEER", "GATHER_NONE", "device_mem_info", "render_image", "square_batches", "batch_window", "n_batches", "shard_rows",
            "shard_global_rows", "write_png", "write_ppm", "write_pfm", "device_count", "YahrError",
-           "SPLIT_MIDPOINT", "SPLIT_SAH", "TRAVERSE_AUTO", "TRAVERSE_LANE", "TRAVERSE_PACKET", "TRAVERSE_HYBRID", "TRAVERSE_STREAM",
+           "SPLIT_MIDPOINT", "SPLIT_SAH", "TRAVERSE_AUTO", "TRAVERSE_LANE", "TRAVERSE_PACKET", "TRAVERSE_HYBRID", "TRAVERSE_STREAM", "TRAVERSE_STACK", "TRAVERSE_HYBRID_STACK", "TRAVERSE_ORDERED",
            "TILES_WAVE", "TILES_REFERENCE", "TUNE_XCD_BANDS", "TUNE_CENTRE_FIRST", "TUNE_REGROUP", "TUNE_ONE_PIXEL_PER_LANE"]
 
 
@@ -208,7 +208,7 @@ class Scene:
 
 
 def make_opts(spp=1, seed=0, traverse=TRAVERSE_AUTO, tiles=TILES_WAVE, n_batches=0, collect_stats=False,
-              n_shards=1, shard=0, strip_rows=8, tuning=0, frames=1, frame_rows=0):
+              n_shards=1, shard=0, strip_rows=8, tuning=0, frames=1, frame_rows=0, stream_walker=0):
     o = RenderOpts()
     lib.yahr_default_opts(C.byref(o))
     o.spp, o.seed, o.traverse, o.tiles, o.n_batches = spp, seed, traverse, tiles, n_batches
@@ -217,6 +217,7 @@ def make_opts(spp=1, seed=0, traverse=TRAVERSE_AUTO, tiles=TILES_WAVE, n_batches
     o.tuning = tuning
     o.frames = frames
     o.frame_rows = frame_rows
+    o.stream_walker = stream_walker
     return o
 
 

@@ -12,6 +12,7 @@ ERR_NAMES = {-1: "YAHR_E_ARG", -2: "YAHR_E_PARSE", -3: "YAHR_E_IO", -4: "YAHR_E_
 
 SPLIT_MIDPOINT, SPLIT_SAH = 0, 1
 TRAVERSE_AUTO, TRAVERSE_LANE, TRAVERSE_PACKET, TRAVERSE_HYBRID, TRAVERSE_STREAM = 0, 1, 2, 3, 4
+TRAVERSE_STACK, TRAVERSE_HYBRID_STACK, TRAVERSE_ORDERED = 5, 6, 7
 TILES_WAVE, TILES_REFERENCE = 0, 1
 GATHER_AUTO, GATHER_RCCL, GATHER_PEER, GATHER_NONE = 0, 1, 2, 3
 TUNE_XCD_BANDS, TUNE_CENTRE_FIRST, TUNE_REGROUP, TUNE_ONE_PIXEL_PER_LANE = 1, 2, 4, 8      # yahr_render_opts.tuning bits (diagnostics)
@@ -58,7 +59,7 @@ class RenderOpts(C.Structure):
     _fields_ = [("spp", C.c_int32), ("seed", C.c_uint32), ("traverse", C.c_int32), ("tiles", C.c_int32),
                 ("n_batches", C.c_int32), ("collect_stats", C.c_int32),
                 ("n_shards", C.c_int32), ("shard", C.c_int32), ("strip_rows", C.c_int32),
-                ("tuning", C.c_int32), ("frames", C.c_int32), ("frame_rows", C.c_int32), ("reserved", C.c_int32 * 4)]
+                ("tuning", C.c_int32), ("frames", C.c_int32), ("frame_rows", C.c_int32), ("stream_walker", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class Stats(C.Structure):

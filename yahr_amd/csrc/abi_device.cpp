@@ -23,6 +23,7 @@ struct yahr_ctx {
   int width = 0, height = 0;
   void *d_nodes = nullptr, *d_prims = nullptr, *d_normals = nullptr, *d_mats = nullptr, *d_lights = nullptr;
   void *d_cold = nullptr;
+  void *d_pairs = nullptr;                // child-pair records of the stack walkers (render_kernel.hpp: DScene::pairs), or NULL
   DCold cold_host{};
   DCold *d_cams = nullptr; int n_cams = 0;
   int *d_row_order = nullptr; int row_order_n = 0;
@@ -140,8 +141,54 @@ int pick_mode(int traverse, int auto_mode = TRAV_PACKET) {
     case YAHR_TRAVERSE_PACKET: return TRAV_PACKET;
     case YAHR_TRAVERSE_HYBRID: return TRAV_ADAPTIVE;
     case YAHR_TRAVERSE_STREAM: return TRAV_STREAM;
+    // the wavefront form with a named walker for its secondary rays
+    case YAHR_TRAVERSE_STACK: case YAHR_TRAVERSE_HYBRID_STACK: case YAHR_TRAVERSE_ORDERED: return TRAV_STREAM;
     default: return auto_mode;       // YAHR_TRAVERSE_AUTO: chosen per scene in yahr_ctx_create
   }
+}
+
+// Child-pair records of the stack walkers (render_kernel.hpp: DScene::pairs) from the flattened tree: two 32-byte child
+// records per interior node, in DFS order of the interior nodes.  Returns false -- the scene then simply has no pair
+// records and every walker uses the node array -- unless the tree is a proper binary tree in DFS order whose every
+// interior box is EXACTLY the join of its children's boxes (Culling.hs:39; a foreign host may hand over looser boxes)
+// and every box is finite with lo <= hi (the stack walker re-derives a popped node's box from its children's and
+// relies on the monotonicity of the NaN-free slab test).
+bool build_pairs(const yahr_scene *s, std::vector<yahr_node> &halves, int &levels) {
+  const int32_t n = s->n_nodes;
+  if (n < 3 || s->nodes[0].b >= 0) return false;
+  std::vector<int32_t> rank((size_t)n, -1), dep((size_t)n, -1);
+  int32_t n_int = 0;
+  for (int32_t i = 0; i < n; ++i) if (s->nodes[i].b < 0) rank[(size_t)i] = n_int++;
+  halves.assign((size_t)n_int * 2, yahr_node{});
+  dep[0] = 0;
+  int32_t deepest = 0;
+  auto skip_of = [&](int32_t i) { return s->nodes[i].b >= 0 ? i + 1 : s->nodes[i].a; };
+  auto child = [&](int32_t c) {
+    yahr_node h = s->nodes[c];
+    if (h.b < 0) { h.a = rank[(size_t)c]; h.b = -1 - c; }
+    return h;
+  };
+  for (int32_t i = 0; i < n; ++i) {
+    const yahr_node &nd = s->nodes[i];
+    if (dep[(size_t)i] < 0) return false;                    // not reached from the root
+    for (int k = 0; k < 3; ++k)
+      if (!std::isfinite(nd.lo[k]) || !std::isfinite(nd.hi[k]) || !(nd.lo[k] <= nd.hi[k])) return false;
+    if (nd.b >= 0) continue;
+    const int32_t l = i + 1;
+    if (l >= n) return false;
+    const int32_t r = skip_of(l);
+    if (r <= l || r >= n || skip_of(r) != nd.a) return false;
+    const yahr_node &a = s->nodes[l], &b = s->nodes[r];
+    for (int k = 0; k < 3; ++k)
+      if (!(nd.lo[k] == std::fmin(a.lo[k], b.lo[k])) || !(nd.hi[k] == std::fmax(a.hi[k], b.hi[k]))) return false;
+    dep[(size_t)l] = dep[(size_t)r] = dep[(size_t)i] + 1;
+    if (dep[(size_t)l] > deepest) deepest = dep[(size_t)l];
+    halves[2 * (size_t)rank[(size_t)i]] = child(l);
+    halves[2 * (size_t)rank[(size_t)i] + 1] = child(r);
+  }
+  levels = deepest > 0 ? deepest : 1;                      // a node at depth d has at most d pending right siblings
+  // 256 B of LDS per level and wavefront: beyond 48 levels (12 KiB) the stack costs more occupancy than it saves fetches
+  return levels <= 48 && (uint64_t)n_int * 64 <= 0xffffffffULL;
 }
 
 // AUTO policy.  Measured per frame at 1080p (ms: lane / packet / adaptive): pseudo-bunny (largest leaf 70)
@@ -253,6 +300,13 @@ int yahr_ctx_create(const yahr_scene *s, int device, yahr_ctx **out) {
   d.cold = (const DCold *)c->d_cold;
   d.n_nodes = s->n_nodes; d.n_prims = s->n_prims; d.n_mats = s->n_mats; d.n_lights = s->n_lights;
   d.depth = s->depth;
+  {
+    std::vector<yahr_node> halves; int levels = 0;
+    if (!std::getenv("YAHR_NO_PAIRS") && build_pairs(s, halves, levels)) {
+      if ((rc = upload(&c->d_pairs, halves.data(), sizeof(yahr_node) * halves.size()))) return rc;
+      d.pairs = (const float4 *)c->d_pairs; d.stack_levels = levels;
+    }
+  }
   c->auto_mode = auto_mode_for(s);
   d.boxes_finite = 1;
   for (int32_t i = 0; i < s->n_nodes && d.boxes_finite; ++i)
@@ -267,7 +321,7 @@ void yahr_ctx_destroy(yahr_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipFree(c->d_nodes); (void)hipFree(c->d_prims); (void)hipFree(c->d_normals); (void)hipFree(c->d_mats);
-  (void)hipFree(c->d_lights); (void)hipFree(c->d_ctr); (void)hipFree(c->d_windows); (void)hipFree(c->d_cold);
+  (void)hipFree(c->d_lights); (void)hipFree(c->d_ctr); (void)hipFree(c->d_windows); (void)hipFree(c->d_cold); (void)hipFree(c->d_pairs);
   (void)hipFree(c->d_cams); (void)hipFree(c->d_row_order); (void)hipFree(c->d_stream); (void)hipFree(c->d_qcount);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -455,13 +509,24 @@ int yahr_ctx_render(yahr_ctx *c, int32_t row0, int32_t row1, const yahr_render_o
     const bool can = rp.tile_mode == 0 && !regroup && rp.row_order == nullptr && !rp.xcd_swizzle;
     if (can) band_rows = stream_band_rows(c, rp.n_local_rows, tile_h, o.spp, c->ds.depth);
     if (band_rows == 0) {
-      if (o.traverse == YAHR_TRAVERSE_STREAM) {
+      if (o.traverse == YAHR_TRAVERSE_STREAM || o.traverse >= YAHR_TRAVERSE_STACK) {
         set_error("stream traversal needs wave tiles, no tuning bits, and device memory for the queues of one tile row");
         return YAHR_E_ARG;
       }
       mode = TRAV_ADAPTIVE;                                                // AUTO: the fused kernel
     }
   }
+  // walker of the stream form's secondary rays: the context's choice, or the one the caller names
+  int secondary = c->stream_secondary;
+  if (o.traverse == YAHR_TRAVERSE_STACK) secondary = TRAV_STACK;
+  else if (o.traverse == YAHR_TRAVERSE_HYBRID_STACK) secondary = TRAV_ADAPT_STACK;
+  else if (o.traverse == YAHR_TRAVERSE_ORDERED) secondary = TRAV_ORDERED;
+  else if (o.stream_walker == YAHR_TRAVERSE_LANE) secondary = TRAV_LANE;
+  else if (o.stream_walker == YAHR_TRAVERSE_PACKET) secondary = TRAV_PACKET;
+  else if (o.stream_walker == YAHR_TRAVERSE_HYBRID) secondary = TRAV_ADAPTIVE;
+  else if (o.stream_walker == YAHR_TRAVERSE_STACK) secondary = TRAV_STACK;
+  else if (o.stream_walker == YAHR_TRAVERSE_HYBRID_STACK) secondary = TRAV_ADAPT_STACK;
+  else if (o.stream_walker == YAHR_TRAVERSE_ORDERED) secondary = TRAV_ORDERED;
   HIP_TRY(hipEventRecord(c->ev0, st));
   if (mode == TRAV_STREAM) {
     const int frames = rp.frames;
@@ -484,7 +549,7 @@ int yahr_ctx_render(yahr_ctx *c, int32_t row0, int32_t row1, const yahr_render_o
           const int band_tiles = ((sp.band_rows + tile_h - 1) / tile_h) * rp.tiles_x;
           HIP_TRY(hipMemsetAsync(c->d_qcount, 0, sizeof(unsigned) * (size_t)(c->ds.depth + 1), st));
           HIP_TRY(hipMemsetAsync(sp.hist, 0, sizeof(unsigned) * YD_SORT_CELLS * (size_t)(c->ds.depth + 1), st));
-          HIP_TRY(yahr_dev::launch_stream_pass(c->ds, rp, sp, c->stream_secondary, band_tiles,
+          HIP_TRY(yahr_dev::launch_stream_pass(c->ds, rp, sp, secondary, band_tiles,
                                                d_rgb + (size_t)f * stride + (size_t)lv0 * (size_t)c->width * 3, c->d_ctr,
                                                o.collect_stats != 0, st));
         }
@@ -558,13 +623,16 @@ static int ray_query(yahr_ctx *c, int32_t n, const float *rays, int which, int t
   HIP_TRY(hipMemcpy(d_rays.p, rays, sizeof(float) * 7 * (size_t)n, hipMemcpyHostToDevice));
   int mode = pick_mode(traverse, c->auto_mode);
   if (mode == TRAV_STREAM) mode = TRAV_ADAPTIVE;            // single rays: the stream form is a whole-image pipeline
+  const int walker = traverse == YAHR_TRAVERSE_STACK ? TRAV_STACK : traverse == YAHR_TRAVERSE_HYBRID_STACK ? TRAV_ADAPT_STACK
+                     : traverse == YAHR_TRAVERSE_ORDERED ? TRAV_ORDERED : 0;    // closest / first hit on the pair records
   if (which == 2) {
     HIP_TRY(d_f.alloc(sizeof(float) * 3 * (size_t)n));
     HIP_TRY(yahr_dev::launch_radiance(c->ds, mode, n, d_rays.as<float>(), d_f.as<float>(), c->d_ctr, nullptr));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(fout, d_f.p, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost));
   } else {
-    if (mode == TRAV_ADAPTIVE) mode = TRAV_PACKET;
+    if (mode == TRAV_ADAPTIVE && traverse != YAHR_TRAVERSE_HYBRID) mode = TRAV_PACKET;
+    if (walker) mode = walker;
     HIP_TRY(d_i.alloc(sizeof(int) * (size_t)n));
     HIP_TRY(d_f.alloc(sizeof(float) * (size_t)n));
     HIP_TRY(yahr_dev::launch_trace(c->ds, mode, n, d_rays.as<float>(), which == 1, d_i.as<int>(), d_f.as<float>(), nullptr));

@@ -81,6 +81,20 @@ YD unsigned long long slab_mask_fast(V3 lo, V3 hi, V3 o, V3 inv, float tmax) {
   const float tfar = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax));
   return __builtin_amdgcn_fcmpf(tnear, tfar, 13);                       // FCMP_ULE: !(tnear > tfar)
 }
+// slab_hit_fast that also hands out the entry distance (near-first ordering of the opt-in ordered walker)
+YD bool slab_near_fast(V3 lo, V3 hi, V3 o, V3 inv, float tmax, float &tnear) {
+  const float t0x = (lo.x - o.x) * inv.x, t1x = (hi.x - o.x) * inv.x;
+  const float t0y = (lo.y - o.y) * inv.y, t1y = (hi.y - o.y) * inv.y;
+  const float t0z = (lo.z - o.z) * inv.z, t1z = (hi.z - o.z) * inv.z;
+  tnear = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), 0.0f));
+  const float tfar = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax));
+  return !(tnear > tfar);
+}
+// AABBs.join (AABBs.hs:24-27) of two finite boxes: component-wise min / max -- no rounding, so a parent's box is
+// recovered EXACTLY from its children's (Culling.hs:39 builds it as that join); the sign of a zero may differ, which
+// no comparison of the slab test sees
+YD V3 vmin(V3 a, V3 b) { return v3(fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z)); }
+YD V3 vmax(V3 a, V3 b) { return v3(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z)); }
 YD bool finite_nonzero(float x) { const float a = fabsf(x); return (a > 0.0f) & (a < __builtin_huge_valf()); }
 YD bool finite_f(float x) { return fabsf(x) < __builtin_huge_valf(); }
 YD bool slab_safe(V3 o, V3 inv) {
@@ -102,6 +116,18 @@ YD bool tri_candidate(V3 p0, V3 e1, V3 e2, V3 o, V3 u, float tmax, float &t, flo
   float b0 = (1.0f - b1) - b2;
   return (b0 >= 0.0f) & (b0 <= 1.0f) & (b1 >= 0.0f) & (b1 <= 1.0f) & (b2 >= 0.0f) & (b2 <= 1.0f) &
          (t > 0.0f) & (t <= tmax);
+}
+// the same without the `t <= tMax` term (the ordered walker applies its own tie rule to it)
+YD bool tri_candidate_open(V3 p0, V3 e1, V3 e2, V3 o, V3 u, float &t, float &b1, float &b2) {
+  V3 s = o - p0;
+  V3 s1 = cross(u, e2);
+  V3 s2 = cross(s, e1);
+  float inv = 1.0f / dot(s1, e1);
+  t = dot(s2, e2) * inv;
+  b1 = dot(s1, s) * inv;
+  b2 = dot(s2, u) * inv;
+  float b0 = (1.0f - b1) - b2;
+  return (b0 >= 0.0f) & (b0 <= 1.0f) & (b1 >= 0.0f) & (b1 <= 1.0f) & (b2 >= 0.0f) & (b2 <= 1.0f) & (t > 0.0f);
 }
 // The same test cut in two for the packet walker (identical operations and values, only regrouped): stage 1
 // needs s, s1, the determinant and its reciprocal and yields b1 with its range test; when no lane of the
@@ -155,6 +181,28 @@ YD bool sphere_hit(V3 c, float r, V3 o, V3 u, float tmax, float &t) {
   float t1 = ((-b) + sq) / (2.0f * a);
   if (t0 > 0.0f && t0 <= tmax) { t = t0; return true; }
   if (t1 > 0.0f && t1 <= tmax) { t = t1; return true; }
+  return false;
+}
+
+// Acceptance of a hit distance when primitives are NOT visited in the reference's order (ordered walker).  In the
+// reference's fixed order `t <= tMax` makes the LATER primitive win an exact tie (Rays.hs:39-46); visited in any other
+// order the same winner needs: strictly nearer, or equally near and later in that order (`idx` = leaf-order record
+// index = position in the reference's order; best = -1 while tMax is still the ray's own limit).
+YD bool accept_ordered(float t, float tmax, int idx, int best) { return (t < tmax) | ((t == tmax) & (idx > best)); }
+YD bool sphere_hit_ordered(V3 c, float r, V3 o, V3 u, float tmax, int idx, int best, float &t) {
+  V3 d = o - c;
+  float a = dot(u, u);
+  float b = dot(vof(2.0f) * d, u);
+  float cc = dot(d, d) - r * r;
+  float delta = b * b - (4.0f * a) * cc;
+  if (delta < 0.0f) return false;
+  float sq = sqrtf(delta);
+  float t0 = ((-b) - sq) / (2.0f * a);
+  float t1 = ((-b) + sq) / (2.0f * a);
+  // the reference takes the first root inside (0, tMax]; a root beyond the current best distance is "outside" there
+  // too, so the same root is chosen and then put to the tie rule
+  if (t0 > 0.0f && t0 <= tmax) { t = t0; return accept_ordered(t0, tmax, idx, best); }
+  if (t1 > 0.0f && t1 <= tmax) { t = t1; return accept_ordered(t1, tmax, idx, best); }
   return false;
 }
 

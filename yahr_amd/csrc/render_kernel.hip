@@ -32,6 +32,8 @@
 //   * the triangle test is cut in two stages with a wave-uniform exit between them.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "device_math.hpp"
 #include "render_kernel.hpp"
 
@@ -114,18 +116,23 @@ YD bool tri_accept(const DScene &sc, int idx, V3 u, float t, float b1, float b2,
   return true;
 }
 
-// one primitive against one ray, lane walker form
-template <bool STATS>
+// one primitive against one ray, lane walker form.  ORDERED: primitives arrive in another order than the reference's,
+// so an exact tie goes to the later record instead of to the later visit (device_math.hpp: accept_ordered)
+template <bool STATS, bool ORDERED = false>
 YD bool test_prim_lane(const DScene &sc, int idx, const PrimRec &p, V3 o, V3 u, float &tmax, Hit &hit, Counters &c) {
   if (__float_as_int(p.r1.w) == 0) {
     if (STATS) c.tri++;
     float t, b1, b2;
-    if (!tri_candidate(xyz(p.r0), xyz(p.r1), xyz(p.r2), o, u, tmax, t, b1, b2)) return false;
+    if (ORDERED) {
+      if (!tri_candidate_open(xyz(p.r0), xyz(p.r1), xyz(p.r2), o, u, t, b1, b2)) return false;
+      if (!accept_ordered(t, tmax, idx, hit.prim)) return false;
+    } else if (!tri_candidate(xyz(p.r0), xyz(p.r1), xyz(p.r2), o, u, tmax, t, b1, b2)) return false;
     return tri_accept(sc, idx, u, t, b1, b2, tmax, hit);
   }
   if (STATS) c.sph++;
   float t;
-  if (!sphere_hit(xyz(p.r0), p.r1.x, o, u, tmax, t)) return false;
+  if (ORDERED ? !sphere_hit_ordered(xyz(p.r0), p.r1.x, o, u, tmax, idx, hit.prim, t)
+              : !sphere_hit(xyz(p.r0), p.r1.x, o, u, tmax, t)) return false;
   hit.prim = idx; hit.t = t; hit.b1 = 0.0f; hit.b2 = 0.0f; tmax = t;
   return true;
 }
@@ -219,6 +226,147 @@ YD void traverse_lane(const DScene &sc, bool active, bool any_hit, V3 o, V3 u, f
   const bool fast = sc.boxes_finite != 0 && !wany(active & !slab_safe(o, inv));
   if (fast) lane_loop<STATS, true>(sc, active ? 0 : sc.n_nodes, any_hit, o, u, inv, tmax, hit, c);
   else lane_loop<STATS, false>(sc, active ? 0 : sc.n_nodes, any_hit, o, u, inv, tmax, hit, c);
+}
+
+// ---- stack walker: lane walker on child-pair records with an LDS stack of pending right siblings ----------------
+// The lane walker above fetches ONE node per dependent round trip and learns only from that node where to go next.
+// Here an interior node's record holds BOTH children (render_kernel.hpp: DScene::pairs), so one round trip yields two
+// box tests, and a right child that must wait for the left subtree (Culling.hs:24-25: box, left, cut ray, right) waits
+// as a 4-byte entry on a per-lane stack in LDS ("LDS-staged node stacks") instead of being found again by a skip link:
+//   entry >= 0        an interior child: the rank of its own pair record
+//   entry <  0        a leaf child: ~(2 * rank of the parent + side) = the half record holding its box, count, first primitive
+//   YD_DEAD           counting builds only: a right child whose box test is known to fail (the reference still counts it)
+// EXACTNESS.  The reference tests the right child's box when it gets there, with the tMax left behind by the left
+// subtree.  In the NaN-free slab form (the only one this walker runs in) that test is `near <= far_box && near <= tMax`
+// with min / max exact, so it is MONOTONE in tMax: a box that fails now fails for every smaller tMax -- such a child is
+// never pushed -- and a box that passes now passes later as long as tMax has not changed.  If tMax did change in
+// between (a hit was accepted: the per-lane watermark `stale` = stack height at the last change; everything below it
+// was pushed before), the popped child is tested again with the tMax of that moment, exactly the reference's test: a
+// leaf child from its half record, an interior child from the join of its two children's boxes, which IS its box
+// (Culling.hs:39; min / max do not round; the host verifies it for every node before it hands out pair records).
+// So every ray performs the reference's box and primitive tests with the reference's operands in the reference's
+// order; only the fetches are regrouped.  Counting builds count a box test when the reference performs it: the left
+// child's at the pair, the right child's (and the root's) at the pop.
+#define YD_DEAD ((int)0x80000000)
+#define YD_NONE ((int)0x80000001)          /* ~0x7ffffffe: no half record has that index */
+template <bool STATS, bool ORDERED>
+YD void stack_loop(const DScene &sc, int *stk, int first, int sp, bool any_hit, V3 o, V3 u, V3 inv, float tmax, Hit &hit,
+                   Counters &c) {
+  // stk = this lane's column of the wavefront's stack (64 ints per level); entries [0, sp) are pending and count as
+  // pushed before the last change of tMax.  `first` (YD_NONE: nothing) is the entry on top of them, handed over in a
+  // register so that the stack needs one level less: the node a traversal starts at -- the root (entry 0), or the node
+  // at which the packet walker handed the lane over; it tests its own box like a popped stale entry.
+  int stale = sp, cur = -1;                            // cur >= 0: pair to process next without a pop
+  int pb = -1, pa = 0;
+  for (;;) {
+    const unsigned long long m_parked = __builtin_amdgcn_sicmp(pb, 0, 39);                       // pb >= 0
+    int todo = cur > sp - 1 ? cur : sp - 1;                                                      // cur >= 0 || sp > 0
+    todo = first != YD_NONE ? 0 : todo;                                                          // || a first entry
+    const unsigned long long m_search = __builtin_amdgcn_sicmp(todo, 0, 39) & ~m_parked;
+    const bool searching = __builtin_amdgcn_inverse_ballot_w64(m_search);
+    const int ns = __builtin_popcountll(m_search);
+    const bool parked = m_parked != 0ULL;
+    if (ns == 0 && !parked) break;
+    if (ns >= YD_LEAF_SEARCHERS || !parked) {                   // node step (wave-uniform choice)
+      if (searching) {
+        int e = cur; bool self = false;
+        if (first != YD_NONE) {                                 // the node the traversal starts at
+          e = first; first = YD_NONE; self = true;
+          if (STATS && !ORDERED) c.box++;
+        } else if (e < 0) {                                     // pop
+          --sp; e = stk[sp * 64];
+          self = sp < stale; stale = self ? sp : stale;
+          if (STATS && !ORDERED) c.box++;                       // the reference tests this child's box now
+        }
+        cur = -1;
+        if (!STATS || ORDERED || e != YD_DEAD) {
+          const bool is_pair = e >= 0;
+          const float4 *q = (const float4 *)((const char *)sc.pairs + (is_pair ? ((unsigned)e << 6) : ((unsigned)(~e) << 5)));
+          const float4 a0 = q[0], a1 = q[1];                    // left child, or the popped leaf child itself
+          float4 a2 = a0, a3 = a1;
+          if (is_pair) { a2 = q[2]; a3 = q[3]; }
+          bool go = true;
+          if (is_pair & self) {                                 // the popped node's own box = join of its children's
+            if (STATS && ORDERED) c.box++;
+            go = slab_hit_fast(vmin(xyz(a0), xyz(a2)), vmax(xyz(a1), xyz(a3)), o, inv, tmax);
+          }
+          if (go) {
+            float n0, n1;
+            bool h0 = slab_near_fast(xyz(a0), xyz(a1), o, inv, tmax, n0);
+            bool h1 = is_pair & slab_near_fast(xyz(a2), xyz(a3), o, inv, tmax, n1);
+            int c0a = __float_as_int(a0.w), c0b = __float_as_int(a1.w), c1a = __float_as_int(a2.w), c1b = __float_as_int(a3.w);
+            if (STATS) c.box += ORDERED ? (is_pair ? 2u : 1u) : (is_pair ? 1u : 0u);
+            if (is_pair) {
+              int s1 = 1;                                       // side of the child that may have to wait
+              // ORDERED: the nearer child first (the right one only if strictly nearer).  Reference order: when the
+              // left child is missed the right one is next, tested with this very tMax -- no detour over the stack
+              if (ORDERED ? (h1 & (!h0 | (n1 < n0))) : !h0) {
+                if (STATS && !ORDERED) c.box++;
+                const bool th = h0; h0 = h1; h1 = th;
+                int ti = c0a; c0a = c1a; c1a = ti; ti = c0b; c0b = c1b; c1b = ti;
+                s1 = 0;
+              }
+              if (h1) stk[64 * sp++] = c1b >= 0 ? ~(2 * e + s1) : c1a;
+              else if (STATS && !ORDERED && s1 == 1) stk[64 * sp++] = YD_DEAD;
+            }
+            if (h0) { if (c0b >= 0) { pb = c0b; pa = c0a; } else cur = c0a; }
+          }
+        }
+      }
+    } else if (pb >= 0) {                                       // leaf step
+      for (int k = 0; k < pa; ++k) {
+        const PrimRec p = load_prim(sc, pb + k);
+        if (test_prim_lane<STATS, ORDERED>(sc, pb + k, p, o, u, tmax, hit, c)) {
+          if (any_hit) { sp = 0; cur = -1; break; }
+          stale = sp;                                           // tMax changed: what is pending was pushed before
+        }
+      }
+      pb = -1;
+    }
+  }
+}
+
+// Stack of the pending right siblings of DFS node j (all of them "stale": tested on the pop) and, in `first`, the entry of
+// node j itself: what a lane needs to continue at node j a traversal that the packet walker began.  Walks down from the
+// root through the pair records: the interior child record carries -1 - its DFS index, a leaf right child is the last
+// node of its parent's subtree.  At most one trip per tree level.
+YD int stack_descend(const DScene &sc, int *stk, int j, int &first) {
+  const int n = sc.n_nodes;
+  first = YD_NONE;
+  if (j >= n) return 0;
+  if (j == 0) { first = 0; return 0; }
+  int sp = 0, k = 0, p = 0, end = n;
+  for (;;) {
+    const float4 *q = (const float4 *)((const char *)sc.pairs + ((unsigned)k << 6));
+    const int la = __float_as_int(q[0].w), lb = __float_as_int(q[1].w), ra = __float_as_int(q[2].w), rb = __float_as_int(q[3].w);
+    const int l_idx = p + 1, r_idx = rb >= 0 ? end - 1 : -1 - rb;
+    const int l_ent = lb >= 0 ? ~(2 * k) : la, r_ent = rb >= 0 ? ~(2 * k + 1) : ra;
+    if (j < r_idx) {
+      stk[64 * sp++] = r_ent;
+      if (j <= l_idx || lb >= 0) { first = l_ent; break; }
+      k = la; p = l_idx; end = r_idx;
+    } else {
+      if (j == r_idx || rb >= 0) { first = r_ent; break; }
+      k = ra; p = r_idx;
+    }
+  }
+  return sp;
+}
+
+// can this wavefront run the stack walker?  (pair records exist, NaN-free slab form legal for every active lane)
+YD bool stack_ok(const DScene &sc, bool active, V3 o, V3 inv) {
+  return sc.pairs != nullptr && sc.boxes_finite != 0 && !wany(active & !slab_safe(o, inv));
+}
+
+template <bool STATS, bool ORDERED>
+YD void traverse_stack(const DScene &sc, int *stk, bool active, bool any_hit, V3 o, V3 u, float tmax, Hit &hit, Counters &c) {
+  const V3 inv = v3(1.0f / u.x, 1.0f / u.y, 1.0f / u.z);
+  hit.prim = -1; hit.t = 0.0f; hit.b1 = 0.0f; hit.b2 = 0.0f;
+  if (stack_ok(sc, active, o, inv)) {
+    stack_loop<STATS, ORDERED>(sc, stk, active ? 0 : YD_NONE, 0, any_hit, o, u, inv, tmax, hit, c);   // from the root's pair
+  } else {
+    lane_loop<STATS, false>(sc, active ? 0 : sc.n_nodes, any_hit, o, u, inv, tmax, hit, c);
+  }
 }
 
 // ---- packet walker ------------------------------------------------------------------------------
@@ -365,8 +513,10 @@ YD int packet_loop(const DScene &sc, bool active, V3 o, V3 u, V3 inv, float &tma
 
 // ADAPT: packet while the rays stay coherent, then every lane on its own.  Both halves perform, per ray, the
 // reference's tests in the reference's order, so where the hand-off happens cannot change a result.
-template <bool STATS, bool ADAPT>
-YD void traverse_packet(const DScene &sc, bool active, bool any_hit, V3 o, V3 u, float tmax, Hit &hit, Counters &c) {
+// STK (ADAPT only): the lanes finish on the stack walker when the wavefront may run it (`stk` = the lane's LDS stack)
+template <bool STATS, bool ADAPT, bool STK = false>
+YD void traverse_packet(const DScene &sc, bool active, bool any_hit, V3 o, V3 u, float tmax, Hit &hit, Counters &c,
+                        int *stk = nullptr) {
   V3 inv = v3(1.0f / u.x, 1.0f / u.y, 1.0f / u.z);
   hit.prim = -1; hit.t = 0.0f; hit.b1 = 0.0f; hit.b2 = 0.0f;
   const int n = sc.n_nodes;
@@ -386,8 +536,15 @@ YD void traverse_packet(const DScene &sc, bool active, bool any_hit, V3 o, V3 u,
   }
   if (ADAPT && i < n) {
     // a lane that already has its first hit in any-hit mode is parked at YD_DONE >= n
-    if (fast) lane_loop<STATS, true>(sc, wake > i ? wake : i, any_hit, o, u, inv, tmax, hit, c);
-    else lane_loop<STATS, false>(sc, wake > i ? wake : i, any_hit, o, u, inv, tmax, hit, c);
+    const int j = wake > i ? wake : i;
+    if (STK && fast && sc.pairs != nullptr) {
+      // the lane's pending right siblings and node j itself, rebuilt from the pair records; all of them are tested on
+      // the pop with the tMax of that moment, like every box the lane has not seen yet
+      int first;
+      const int sp = stack_descend(sc, stk, j, first);
+      stack_loop<STATS, false>(sc, stk, first, sp, any_hit, o, u, inv, tmax, hit, c);
+    } else if (fast) lane_loop<STATS, true>(sc, j, any_hit, o, u, inv, tmax, hit, c);
+    else lane_loop<STATS, false>(sc, j, any_hit, o, u, inv, tmax, hit, c);
   }
 }
 
@@ -395,10 +552,14 @@ YD void traverse_packet(const DScene &sc, bool active, bool any_hit, V3 o, V3 u,
 // camera rays share almost their whole path, and the hand-off to the lane walker only costs there (1 M triangles, 16 spp,
 // camera rays alone: adaptive 15.6 ms, packet 11.1 ms).  Which walker runs never changes a result.
 template <int MODE, bool STATS>
-YD void traverse(const DScene &sc, bool active, bool any_hit, bool coherent, V3 o, V3 u, float tmax, Hit &hit, Counters &c) {
+YD void traverse(const DScene &sc, bool active, bool any_hit, bool coherent, V3 o, V3 u, float tmax, Hit &hit, Counters &c,
+                 int *stk = nullptr) {
   if (MODE == TRAV_LANE) traverse_lane<STATS>(sc, active, any_hit, o, u, tmax, hit, c);
+  else if (MODE == TRAV_STACK) traverse_stack<STATS, false>(sc, stk, active, any_hit, o, u, tmax, hit, c);
+  else if (MODE == TRAV_ORDERED) traverse_stack<STATS, true>(sc, stk, active, any_hit, o, u, tmax, hit, c);
   else if (MODE == TRAV_PACKET) traverse_packet<STATS, false>(sc, active, any_hit, o, u, tmax, hit, c);
   else if (coherent) traverse_packet<STATS, false>(sc, active, any_hit, o, u, tmax, hit, c);
+  else if (MODE == TRAV_ADAPT_STACK) traverse_packet<STATS, true, true>(sc, active, any_hit, o, u, tmax, hit, c, stk);
   else traverse_packet<STATS, true>(sc, active, any_hit, o, u, tmax, hit, c);     // TRAV_ADAPTIVE
 }
 
@@ -408,8 +569,8 @@ YD void traverse(const DScene &sc, bool active, bool any_hit, bool coherent, V3 
 // atomics or barriers come before it.  Reached through the pointer fields of the by-value DScene block instead,
 // the same loads silently became per-lane gathers as soon as anything that may write memory preceded them.
 #define YD_SCENE_PARAMS const float4 *__restrict__ a_nodes, const float4 *__restrict__ a_prims, \
-                        const float4 *__restrict__ a_normals
-#define YD_SCENE_BIND DScene sc = sc_in; sc.nodes = a_nodes; sc.prims = a_prims; sc.normals = a_normals;
+                        const float4 *__restrict__ a_normals, const float4 *__restrict__ a_pairs
+#define YD_SCENE_BIND DScene sc = sc_in; sc.nodes = a_nodes; sc.prims = a_prims; sc.normals = a_normals; sc.pairs = a_pairs;
 
 // ---- ray regrouping inside a workgroup of WPB waves ----------------------------------------------
 // Barrier whose fences cover LDS only: a full __syncthreads() fences global memory too, which makes every later
@@ -862,8 +1023,10 @@ __global__ __launch_bounds__(1024) void k_sort_scatter(SParams sp) {
 template <int MODE, bool STATS>
 __global__ __launch_bounds__(64 * YD_LEVEL_WAVES) __attribute__((amdgpu_waves_per_eu(YAHR_WAVES_LANE, 8)))
 void k_stream_level(DScene sc_in, YD_SCENE_PARAMS, SParams sp, unsigned long long *__restrict__ ctr) {
+  extern __shared__ int trav_stack[];                                  // stack walkers: stack_levels x 64 entries per wavefront
   YD_SCENE_BIND
   const int lane = threadIdx.x & 63;
+  int *stk = trav_stack + (size_t)(threadIdx.x >> 6) * 64 * (size_t)sc.stack_levels + lane;
   const int k = sp.level, in = k & 1;
   const unsigned n_in = sp.count[k];
   const unsigned chunk = blockIdx.x * YD_LEVEL_WAVES + (threadIdx.x >> 6);
@@ -900,7 +1063,7 @@ void k_stream_level(DScene sc_in, YD_SCENE_PARAMS, SParams sp, unsigned long lon
     Hit hit;
     // the paths of a wavefront are neighbours in space (Morton order) and a shadow ray's direction follows from its
     // origin: coherent rays, so the adaptive walker stays a packet for them (1 M triangles: 38.3 -> 37.2 ms per frame)
-    traverse<MODE, STATS>(sc, active, true, true, qo, qdir, qt, hit, c);
+    traverse<MODE, STATS>(sc, active, true, true, qo, qdir, qt, hit, c, stk);
     if (valid) direct = direct + ((active && hit.prim < 0) ? cv : vof(0.0f));   // sum = foldl (+) 0, light order
   }
   const V3 r = rd - scale(2.0f * dot(rd, n), n);                       // reflectionDir, Integrators.hs:46-47
@@ -915,7 +1078,7 @@ void k_stream_level(DScene sc_in, YD_SCENE_PARAMS, SParams sp, unsigned long lon
     const V3 ro2 = x + scale(0.001f, r);                               // Integrators.hs:41-43
     if (STATS) c.reflection += lanes(valid);
     Hit hit;
-    traverse<MODE, STATS>(sc, valid, false, false, ro2, r, 1e6f, hit, c);
+    traverse<MODE, STATS>(sc, valid, false, false, ro2, r, 1e6f, hit, c, stk);
     const bool alive = valid && hit.prim >= 0;
     if (STATS) c.shaded += lanes(alive);
     V3 x2 = vof(0.0f), n2 = vof(0.0f), dpdu2 = vof(0.0f);
@@ -980,13 +1143,14 @@ __global__ __launch_bounds__(256) void k_stream_resolve_lanes(RParams rp, SParam
 template <int MODE>
 __global__ __launch_bounds__(64) void k_trace(DScene sc_in, YD_SCENE_PARAMS, int n, const float *__restrict__ rays,
                                               int any_hit, int *__restrict__ prim_out, float *__restrict__ t_out) {
+  extern __shared__ int trav_stack[];
   YD_SCENE_BIND
   const int i = blockIdx.x * 64 + threadIdx.x;
   const bool valid = i < n;
   V3 o = vof(0.0f), d = v3(0, 0, 1); float tmax = 0.0f;
   if (valid) { const float *p = rays + 7 * (size_t)i; o = v3(p[0], p[1], p[2]); d = v3(p[3], p[4], p[5]); tmax = p[6]; }
   Hit h; Counters c = {};
-  traverse<MODE, false>(sc, valid, any_hit != 0, false, o, d, tmax, h, c);
+  traverse<MODE, false>(sc, valid, any_hit != 0, false, o, d, tmax, h, c, trav_stack + threadIdx.x);
   if (valid) {
     prim_out[i] = h.prim >= 0 ? __float_as_int(sc.prims[3 * (size_t)h.prim + 2].w) : -1;
     if (t_out) t_out[i] = h.t;
@@ -1029,8 +1193,8 @@ static hipError_t launch_render_mode(const DScene &sc, const RParams &rp, int n_
   // per-level (w_k, D_k) stack of every thread, then (WPB > 1) the exchange area of traverse_block / block_any
   const size_t lds_bytes = ((size_t)(sc.depth > 0 ? sc.depth : 1) * 6 * 64 * WPB +
                             (WPB > 1 ? 12 * 64 * WPB + 2 * WPB : 0)) * sizeof(float);
-  if (stats) hipLaunchKernelGGL((k_render<MODE, true, WPB>), dim3(n_blocks), dim3(64 * WPB), lds_bytes, st, sc, sc.nodes, sc.prims, sc.normals, rp, out, ctr);
-  else hipLaunchKernelGGL((k_render<MODE, false, WPB>), dim3(n_blocks), dim3(64 * WPB), lds_bytes, st, sc, sc.nodes, sc.prims, sc.normals, rp, out, ctr);
+  if (stats) hipLaunchKernelGGL((k_render<MODE, true, WPB>), dim3(n_blocks), dim3(64 * WPB), lds_bytes, st, sc, sc.nodes, sc.prims, sc.normals, sc.pairs, rp, out, ctr);
+  else hipLaunchKernelGGL((k_render<MODE, false, WPB>), dim3(n_blocks), dim3(64 * WPB), lds_bytes, st, sc, sc.nodes, sc.prims, sc.normals, sc.pairs, rp, out, ctr);
   return hipGetLastError();
 }
 
@@ -1054,24 +1218,34 @@ template <int MODE>
 static void launch_stream_levels(const DScene &sc, SParams sp, int n_level_blocks, unsigned long long *ctr, bool stats,
                                  hipStream_t st) {
   const unsigned sort_blocks = (sp.capacity + 1023u) / 1024u;
+  // the stack walkers keep a per-lane stack of pending right siblings in LDS: stack_levels x 64 entries per wavefront
+  size_t lds = (MODE == TRAV_STACK || MODE == TRAV_ADAPT_STACK || MODE == TRAV_ORDERED)
+                         ? (size_t)sc.stack_levels * 64 * YD_LEVEL_WAVES * sizeof(int) : 0;
+  if (const char *e = getenv("YAHR_DEBUG_LDS")) lds = (size_t)atoi(e);     // occupancy experiments
   for (int k = 0; k < sc.depth; ++k) {
     sp.level = k; sp.last = (k == sc.depth - 1) ? 1 : 0;
     hipLaunchKernelGGL(k_sort_scan, dim3(YD_SORT_CELLS / 1024u), dim3(1024), 0, st, sp);
     hipLaunchKernelGGL(k_sort_scatter, dim3(sort_blocks), dim3(1024), 0, st, sp);
-    if (stats) hipLaunchKernelGGL((k_stream_level<MODE, true>), dim3(n_level_blocks), dim3(64 * YD_LEVEL_WAVES), 0, st, sc, sc.nodes, sc.prims, sc.normals, sp, ctr);
-    else hipLaunchKernelGGL((k_stream_level<MODE, false>), dim3(n_level_blocks), dim3(64 * YD_LEVEL_WAVES), 0, st, sc, sc.nodes, sc.prims, sc.normals, sp, ctr);
+    if (stats) hipLaunchKernelGGL((k_stream_level<MODE, true>), dim3(n_level_blocks), dim3(64 * YD_LEVEL_WAVES), lds, st, sc, sc.nodes, sc.prims, sc.normals, sc.pairs, sp, ctr);
+    else hipLaunchKernelGGL((k_stream_level<MODE, false>), dim3(n_level_blocks), dim3(64 * YD_LEVEL_WAVES), lds, st, sc, sc.nodes, sc.prims, sc.normals, sc.pairs, sp, ctr);
   }
 }
 
 hipError_t launch_stream_pass(const DScene &sc, const RParams &rp, SParams sp, int secondary_mode, int n_blocks, float *out,
                               unsigned long long *ctr, bool stats, hipStream_t st) {
-  if (stats) hipLaunchKernelGGL((k_stream_primary<true>), dim3(n_blocks), dim3(64), 0, st, sc, sc.nodes, sc.prims, sc.normals, rp, sp, ctr);
-  else hipLaunchKernelGGL((k_stream_primary<false>), dim3(n_blocks), dim3(64), 0, st, sc, sc.nodes, sc.prims, sc.normals, rp, sp, ctr);
+  if (stats) hipLaunchKernelGGL((k_stream_primary<true>), dim3(n_blocks), dim3(64), 0, st, sc, sc.nodes, sc.prims, sc.normals, sc.pairs, rp, sp, ctr);
+  else hipLaunchKernelGGL((k_stream_primary<false>), dim3(n_blocks), dim3(64), 0, st, sc, sc.nodes, sc.prims, sc.normals, sc.pairs, rp, sp, ctr);
   // the level launches cover the queue's capacity; wavefronts beyond the queue's length exit at once
   const int n_level_blocks = (int)((sp.capacity + 64u * YD_LEVEL_WAVES - 1u) / (64u * YD_LEVEL_WAVES));
-  if (secondary_mode == TRAV_LANE) launch_stream_levels<TRAV_LANE>(sc, sp, n_level_blocks, ctr, stats, st);
-  else if (secondary_mode == TRAV_PACKET) launch_stream_levels<TRAV_PACKET>(sc, sp, n_level_blocks, ctr, stats, st);
-  else launch_stream_levels<TRAV_ADAPTIVE>(sc, sp, n_level_blocks, ctr, stats, st);
+  // (a scene without pair records runs the stack modes too: they fall back to the skip-link lane walker per wavefront)
+  switch (secondary_mode) {
+    case TRAV_LANE: launch_stream_levels<TRAV_LANE>(sc, sp, n_level_blocks, ctr, stats, st); break;
+    case TRAV_PACKET: launch_stream_levels<TRAV_PACKET>(sc, sp, n_level_blocks, ctr, stats, st); break;
+    case TRAV_STACK: launch_stream_levels<TRAV_STACK>(sc, sp, n_level_blocks, ctr, stats, st); break;
+    case TRAV_ADAPT_STACK: launch_stream_levels<TRAV_ADAPT_STACK>(sc, sp, n_level_blocks, ctr, stats, st); break;
+    case TRAV_ORDERED: launch_stream_levels<TRAV_ORDERED>(sc, sp, n_level_blocks, ctr, stats, st); break;
+    default: launch_stream_levels<TRAV_ADAPTIVE>(sc, sp, n_level_blocks, ctr, stats, st); break;
+  }
   const size_t n_px = (size_t)sp.band_rows * (size_t)rp.width;
   int spp_log2 = 0;
   while ((1 << spp_log2) < rp.spp) ++spp_log2;
@@ -1086,8 +1260,17 @@ hipError_t launch_stream_pass(const DScene &sc, const RParams &rp, SParams sp, i
 hipError_t launch_trace(const DScene &sc, int mode, int n, const float *rays, int any_hit, int *prim_out,
                         float *t_out, hipStream_t st) {
   const int nb = (n + 63) / 64;
-  if (mode == TRAV_LANE) hipLaunchKernelGGL((k_trace<TRAV_LANE>), dim3(nb), dim3(64), 0, st, sc, sc.nodes, sc.prims, sc.normals, n, rays, any_hit, prim_out, t_out);
-  else hipLaunchKernelGGL((k_trace<TRAV_PACKET>), dim3(nb), dim3(64), 0, st, sc, sc.nodes, sc.prims, sc.normals, n, rays, any_hit, prim_out, t_out);
+  const size_t lds = (size_t)sc.stack_levels * 64 * sizeof(int);
+#define YD_TRACE(M, L) hipLaunchKernelGGL((k_trace<M>), dim3(nb), dim3(64), L, st, sc, sc.nodes, sc.prims, sc.normals, sc.pairs, n, rays, any_hit, prim_out, t_out)
+  switch (mode) {
+    case TRAV_LANE: YD_TRACE(TRAV_LANE, 0); break;
+    case TRAV_STACK: YD_TRACE(TRAV_STACK, lds); break;
+    case TRAV_ADAPT_STACK: YD_TRACE(TRAV_ADAPT_STACK, lds); break;
+    case TRAV_ORDERED: YD_TRACE(TRAV_ORDERED, lds); break;
+    case TRAV_ADAPTIVE: YD_TRACE(TRAV_ADAPTIVE, 0); break;
+    default: YD_TRACE(TRAV_PACKET, 0); break;
+  }
+#undef YD_TRACE
   return hipGetLastError();
 }
 
@@ -1095,9 +1278,9 @@ hipError_t launch_radiance(const DScene &sc, int mode, int n, const float *rays,
                            unsigned long long *ctr, hipStream_t st) {
   const int nb = (n + 63) / 64;
   const size_t lds_bytes = (size_t)(sc.depth > 0 ? sc.depth : 1) * 6 * 64 * sizeof(float);
-  if (mode == TRAV_LANE) hipLaunchKernelGGL((k_radiance<TRAV_LANE>), dim3(nb), dim3(64), lds_bytes, st, sc, sc.nodes, sc.prims, sc.normals, n, rays, rgb, ctr);
-  else if (mode == TRAV_PACKET) hipLaunchKernelGGL((k_radiance<TRAV_PACKET>), dim3(nb), dim3(64), lds_bytes, st, sc, sc.nodes, sc.prims, sc.normals, n, rays, rgb, ctr);
-  else hipLaunchKernelGGL((k_radiance<TRAV_ADAPTIVE>), dim3(nb), dim3(64), lds_bytes, st, sc, sc.nodes, sc.prims, sc.normals, n, rays, rgb, ctr);
+  if (mode == TRAV_LANE) hipLaunchKernelGGL((k_radiance<TRAV_LANE>), dim3(nb), dim3(64), lds_bytes, st, sc, sc.nodes, sc.prims, sc.normals, sc.pairs, n, rays, rgb, ctr);
+  else if (mode == TRAV_PACKET) hipLaunchKernelGGL((k_radiance<TRAV_PACKET>), dim3(nb), dim3(64), lds_bytes, st, sc, sc.nodes, sc.prims, sc.normals, sc.pairs, n, rays, rgb, ctr);
+  else hipLaunchKernelGGL((k_radiance<TRAV_ADAPTIVE>), dim3(nb), dim3(64), lds_bytes, st, sc, sc.nodes, sc.prims, sc.normals, sc.pairs, n, rays, rgb, ctr);
   return hipGetLastError();
 }
 

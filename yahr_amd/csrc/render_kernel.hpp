@@ -25,6 +25,14 @@ struct DScene {
   int n_nodes, n_prims, n_mats, n_lights;
   int depth;
   int boxes_finite;        // every node box has finite lo <= hi: enables the NaN-free slab form
+  // Child-pair records for the stack walker (render_kernel.hip: stack_loop): interior node of rank k (k-th interior node
+  // in DFS order; the root is 0) owns 64 B = the records of its LEFT and RIGHT child side by side, 4 float4 words.  A child
+  // record is the child's yahr_node with other links: leaf {lo, count, hi, first primitive} as in `nodes`; interior
+  // {lo, rank of the child, hi, -1 - DFS index of the child}.  NULL when the scene has none (root is a leaf, a box is not
+  // finite, or a node's box is not exactly the join of its children's).  stack_levels = depth of the deepest node = entries
+  // of the per-lane LDS stack of pending right siblings.
+  const float4 *pairs;
+  int stack_levels;
 };
 
 struct RParams {
@@ -79,7 +87,11 @@ struct SParams {
 #endif
 #define YD_SORT_CELLS (1u << YD_SORT_BITS)
 
-enum { TRAV_LANE = 1, TRAV_PACKET = 2, TRAV_ADAPTIVE = 3, TRAV_STREAM = 4 };
+enum { TRAV_LANE = 1, TRAV_PACKET = 2, TRAV_ADAPTIVE = 3, TRAV_STREAM = 4,
+       // walkers of the stream form's level launches (and of the diagnostic ray queries) on the child-pair records:
+       TRAV_STACK = 5,          // every lane on its own with an LDS stack of pending right siblings: reference order
+       TRAV_ADAPT_STACK = 6,    // packet while coherent, then TRAV_STACK
+       TRAV_ORDERED = 7 };      // TRAV_STACK visiting the nearer child first (opt-in: YAHR_TRAVERSE_ORDERED)
 
 enum { CTR_PRIMARY = 0, CTR_REFLECTION, CTR_SHADOW, CTR_SHADED, CTR_BAD_MAT,
        CTR_BOX, CTR_TRI, CTR_SPH, CTR_WAVE_NODES, CTR_WAVE_PRIMS, CTR_WAVE_STAGE1, CTR_WAVE_STAGE2, CTR_COUNT,

@@ -20,10 +20,11 @@ using yahr::set_error;
 struct yahr_ctx {
   int device = 0;
   DScene ds{};
+  DPairs dp{};                            // child-pair records of the stack walkers, or {NULL, 0}
   int width = 0, height = 0;
   void *d_nodes = nullptr, *d_prims = nullptr, *d_normals = nullptr, *d_mats = nullptr, *d_lights = nullptr;
   void *d_cold = nullptr;
-  void *d_pairs = nullptr;                // child-pair records of the stack walkers (render_kernel.hpp: DScene::pairs), or NULL
+  void *d_pairs = nullptr;                // child-pair records of the stack walkers (render_kernel.hpp: DPairs), or NULL
   DCold cold_host{};
   DCold *d_cams = nullptr; int n_cams = 0;
   int *d_row_order = nullptr; int row_order_n = 0;
@@ -147,7 +148,7 @@ int pick_mode(int traverse, int auto_mode = TRAV_PACKET) {
   }
 }
 
-// Child-pair records of the stack walkers (render_kernel.hpp: DScene::pairs) from the flattened tree: two 32-byte child
+// Child-pair records of the stack walkers (render_kernel.hpp: DPairs) from the flattened tree: two 32-byte child
 // records per interior node, in DFS order of the interior nodes.  Returns false -- the scene then simply has no pair
 // records and every walker uses the node array -- unless the tree is a proper binary tree in DFS order whose every
 // interior box is EXACTLY the join of its children's boxes (Culling.hs:39; a foreign host may hand over looser boxes)
@@ -304,7 +305,7 @@ int yahr_ctx_create(const yahr_scene *s, int device, yahr_ctx **out) {
     std::vector<yahr_node> halves; int levels = 0;
     if (!std::getenv("YAHR_NO_PAIRS") && build_pairs(s, halves, levels)) {
       if ((rc = upload(&c->d_pairs, halves.data(), sizeof(yahr_node) * halves.size()))) return rc;
-      d.pairs = (const float4 *)c->d_pairs; d.stack_levels = levels;
+      c->dp.pairs = (const float4 *)c->d_pairs; c->dp.stack_levels = levels;
     }
   }
   c->auto_mode = auto_mode_for(s);
@@ -549,7 +550,7 @@ int yahr_ctx_render(yahr_ctx *c, int32_t row0, int32_t row1, const yahr_render_o
           const int band_tiles = ((sp.band_rows + tile_h - 1) / tile_h) * rp.tiles_x;
           HIP_TRY(hipMemsetAsync(c->d_qcount, 0, sizeof(unsigned) * (size_t)(c->ds.depth + 1), st));
           HIP_TRY(hipMemsetAsync(sp.hist, 0, sizeof(unsigned) * YD_SORT_CELLS * (size_t)(c->ds.depth + 1), st));
-          HIP_TRY(yahr_dev::launch_stream_pass(c->ds, rp, sp, secondary, band_tiles,
+          HIP_TRY(yahr_dev::launch_stream_pass(c->ds, c->dp, rp, sp, secondary, band_tiles,
                                                d_rgb + (size_t)f * stride + (size_t)lv0 * (size_t)c->width * 3, c->d_ctr,
                                                o.collect_stats != 0, st));
         }
@@ -635,7 +636,7 @@ static int ray_query(yahr_ctx *c, int32_t n, const float *rays, int which, int t
     if (walker) mode = walker;
     HIP_TRY(d_i.alloc(sizeof(int) * (size_t)n));
     HIP_TRY(d_f.alloc(sizeof(float) * (size_t)n));
-    HIP_TRY(yahr_dev::launch_trace(c->ds, mode, n, d_rays.as<float>(), which == 1, d_i.as<int>(), d_f.as<float>(), nullptr));
+    HIP_TRY(yahr_dev::launch_trace(c->ds, c->dp, mode, n, d_rays.as<float>(), which == 1, d_i.as<int>(), d_f.as<float>(), nullptr));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(iout, d_i.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
     if (fout) HIP_TRY(hipMemcpy(fout, d_f.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));

@@ -230,7 +230,7 @@ YD void traverse_lane(const DScene &sc, bool active, bool any_hit, V3 o, V3 u, f
 
 // ---- stack walker: lane walker on child-pair records with an LDS stack of pending right siblings ----------------
 // The lane walker above fetches ONE node per dependent round trip and learns only from that node where to go next.
-// Here an interior node's record holds BOTH children (render_kernel.hpp: DScene::pairs), so one round trip yields two
+// Here an interior node's record holds BOTH children (render_kernel.hpp: DPairs), so one round trip yields two
 // box tests, and a right child that must wait for the left subtree (Culling.hs:24-25: box, left, cut ray, right) waits
 // as a 4-byte entry on a per-lane stack in LDS ("LDS-staged node stacks") instead of being found again by a skip link:
 //   entry >= 0        an interior child: the rank of its own pair record
@@ -250,7 +250,7 @@ YD void traverse_lane(const DScene &sc, bool active, bool any_hit, V3 o, V3 u, f
 #define YD_DEAD ((int)0x80000000)
 #define YD_NONE ((int)0x80000001)          /* ~0x7ffffffe: no half record has that index */
 template <bool STATS, bool ORDERED>
-YD void stack_loop(const DScene &sc, int *stk, int first, int sp, bool any_hit, V3 o, V3 u, V3 inv, float tmax, Hit &hit,
+YD void stack_loop(const DScene &sc, const float4 *pairs, int *stk, int first, int sp, bool any_hit, V3 o, V3 u, V3 inv, float tmax, Hit &hit,
                    Counters &c) {
   // stk = this lane's column of the wavefront's stack (64 ints per level); entries [0, sp) are pending and count as
   // pushed before the last change of tMax.  `first` (YD_NONE: nothing) is the entry on top of them, handed over in a
@@ -281,7 +281,7 @@ YD void stack_loop(const DScene &sc, int *stk, int first, int sp, bool any_hit, 
         cur = -1;
         if (!STATS || ORDERED || e != YD_DEAD) {
           const bool is_pair = e >= 0;
-          const float4 *q = (const float4 *)((const char *)sc.pairs + (is_pair ? ((unsigned)e << 6) : ((unsigned)(~e) << 5)));
+          const float4 *q = (const float4 *)((const char *)pairs + (is_pair ? ((unsigned)e << 6) : ((unsigned)(~e) << 5)));
           const float4 a0 = q[0], a1 = q[1];                    // left child, or the popped leaf child itself
           float4 a2 = a0, a3 = a1;
           if (is_pair) { a2 = q[2]; a3 = q[3]; }
@@ -330,14 +330,14 @@ YD void stack_loop(const DScene &sc, int *stk, int first, int sp, bool any_hit, 
 // node j itself: what a lane needs to continue at node j a traversal that the packet walker began.  Walks down from the
 // root through the pair records: the interior child record carries -1 - its DFS index, a leaf right child is the last
 // node of its parent's subtree.  At most one trip per tree level.
-YD int stack_descend(const DScene &sc, int *stk, int j, int &first) {
+YD int stack_descend(const DScene &sc, const float4 *pairs, int *stk, int j, int &first) {
   const int n = sc.n_nodes;
   first = YD_NONE;
   if (j >= n) return 0;
   if (j == 0) { first = 0; return 0; }
   int sp = 0, k = 0, p = 0, end = n;
   for (;;) {
-    const float4 *q = (const float4 *)((const char *)sc.pairs + ((unsigned)k << 6));
+    const float4 *q = (const float4 *)((const char *)pairs + ((unsigned)k << 6));
     const int la = __float_as_int(q[0].w), lb = __float_as_int(q[1].w), ra = __float_as_int(q[2].w), rb = __float_as_int(q[3].w);
     const int l_idx = p + 1, r_idx = rb >= 0 ? end - 1 : -1 - rb;
     const int l_ent = lb >= 0 ? ~(2 * k) : la, r_ent = rb >= 0 ? ~(2 * k + 1) : ra;
@@ -354,16 +354,17 @@ YD int stack_descend(const DScene &sc, int *stk, int j, int &first) {
 }
 
 // can this wavefront run the stack walker?  (pair records exist, NaN-free slab form legal for every active lane)
-YD bool stack_ok(const DScene &sc, bool active, V3 o, V3 inv) {
-  return sc.pairs != nullptr && sc.boxes_finite != 0 && !wany(active & !slab_safe(o, inv));
+YD bool stack_ok(const DScene &sc, const float4 *pairs, bool active, V3 o, V3 inv) {
+  return pairs != nullptr && sc.boxes_finite != 0 && !wany(active & !slab_safe(o, inv));
 }
 
 template <bool STATS, bool ORDERED>
-YD void traverse_stack(const DScene &sc, int *stk, bool active, bool any_hit, V3 o, V3 u, float tmax, Hit &hit, Counters &c) {
+YD void traverse_stack(const DScene &sc, const float4 *pairs, int *stk, bool active, bool any_hit, V3 o, V3 u, float tmax, Hit &hit,
+                       Counters &c) {
   const V3 inv = v3(1.0f / u.x, 1.0f / u.y, 1.0f / u.z);
   hit.prim = -1; hit.t = 0.0f; hit.b1 = 0.0f; hit.b2 = 0.0f;
-  if (stack_ok(sc, active, o, inv)) {
-    stack_loop<STATS, ORDERED>(sc, stk, active ? 0 : YD_NONE, 0, any_hit, o, u, inv, tmax, hit, c);   // from the root's pair
+  if (stack_ok(sc, pairs, active, o, inv)) {
+    stack_loop<STATS, ORDERED>(sc, pairs, stk, active ? 0 : YD_NONE, 0, any_hit, o, u, inv, tmax, hit, c);   // from the root's pair
   } else {
     lane_loop<STATS, false>(sc, active ? 0 : sc.n_nodes, any_hit, o, u, inv, tmax, hit, c);
   }
@@ -516,7 +517,7 @@ YD int packet_loop(const DScene &sc, bool active, V3 o, V3 u, V3 inv, float &tma
 // STK (ADAPT only): the lanes finish on the stack walker when the wavefront may run it (`stk` = the lane's LDS stack)
 template <bool STATS, bool ADAPT, bool STK = false>
 YD void traverse_packet(const DScene &sc, bool active, bool any_hit, V3 o, V3 u, float tmax, Hit &hit, Counters &c,
-                        int *stk = nullptr) {
+                        int *stk = nullptr, const float4 *pairs = nullptr) {
   V3 inv = v3(1.0f / u.x, 1.0f / u.y, 1.0f / u.z);
   hit.prim = -1; hit.t = 0.0f; hit.b1 = 0.0f; hit.b2 = 0.0f;
   const int n = sc.n_nodes;
@@ -537,12 +538,12 @@ YD void traverse_packet(const DScene &sc, bool active, bool any_hit, V3 o, V3 u,
   if (ADAPT && i < n) {
     // a lane that already has its first hit in any-hit mode is parked at YD_DONE >= n
     const int j = wake > i ? wake : i;
-    if (STK && fast && sc.pairs != nullptr) {
+    if (STK && fast && pairs != nullptr) {
       // the lane's pending right siblings and node j itself, rebuilt from the pair records; all of them are tested on
       // the pop with the tMax of that moment, like every box the lane has not seen yet
       int first;
-      const int sp = stack_descend(sc, stk, j, first);
-      stack_loop<STATS, false>(sc, stk, first, sp, any_hit, o, u, inv, tmax, hit, c);
+      const int sp = stack_descend(sc, pairs, stk, j, first);
+      stack_loop<STATS, false>(sc, pairs, stk, first, sp, any_hit, o, u, inv, tmax, hit, c);
     } else if (fast) lane_loop<STATS, true>(sc, j, any_hit, o, u, inv, tmax, hit, c);
     else lane_loop<STATS, false>(sc, j, any_hit, o, u, inv, tmax, hit, c);
   }
@@ -553,13 +554,13 @@ YD void traverse_packet(const DScene &sc, bool active, bool any_hit, V3 o, V3 u,
 // camera rays alone: adaptive 15.6 ms, packet 11.1 ms).  Which walker runs never changes a result.
 template <int MODE, bool STATS>
 YD void traverse(const DScene &sc, bool active, bool any_hit, bool coherent, V3 o, V3 u, float tmax, Hit &hit, Counters &c,
-                 int *stk = nullptr) {
+                 int *stk = nullptr, const float4 *pairs = nullptr) {
   if (MODE == TRAV_LANE) traverse_lane<STATS>(sc, active, any_hit, o, u, tmax, hit, c);
-  else if (MODE == TRAV_STACK) traverse_stack<STATS, false>(sc, stk, active, any_hit, o, u, tmax, hit, c);
-  else if (MODE == TRAV_ORDERED) traverse_stack<STATS, true>(sc, stk, active, any_hit, o, u, tmax, hit, c);
+  else if (MODE == TRAV_STACK) traverse_stack<STATS, false>(sc, pairs, stk, active, any_hit, o, u, tmax, hit, c);
+  else if (MODE == TRAV_ORDERED) traverse_stack<STATS, true>(sc, pairs, stk, active, any_hit, o, u, tmax, hit, c);
   else if (MODE == TRAV_PACKET) traverse_packet<STATS, false>(sc, active, any_hit, o, u, tmax, hit, c);
   else if (coherent) traverse_packet<STATS, false>(sc, active, any_hit, o, u, tmax, hit, c);
-  else if (MODE == TRAV_ADAPT_STACK) traverse_packet<STATS, true, true>(sc, active, any_hit, o, u, tmax, hit, c, stk);
+  else if (MODE == TRAV_ADAPT_STACK) traverse_packet<STATS, true, true>(sc, active, any_hit, o, u, tmax, hit, c, stk, pairs);
   else traverse_packet<STATS, true>(sc, active, any_hit, o, u, tmax, hit, c);     // TRAV_ADAPTIVE
 }
 
@@ -569,8 +570,10 @@ YD void traverse(const DScene &sc, bool active, bool any_hit, bool coherent, V3 
 // atomics or barriers come before it.  Reached through the pointer fields of the by-value DScene block instead,
 // the same loads silently became per-lane gathers as soon as anything that may write memory preceded them.
 #define YD_SCENE_PARAMS const float4 *__restrict__ a_nodes, const float4 *__restrict__ a_prims, \
-                        const float4 *__restrict__ a_normals, const float4 *__restrict__ a_pairs
-#define YD_SCENE_BIND DScene sc = sc_in; sc.nodes = a_nodes; sc.prims = a_prims; sc.normals = a_normals; sc.pairs = a_pairs;
+                        const float4 *__restrict__ a_normals
+#define YD_SCENE_BIND DScene sc = sc_in; sc.nodes = a_nodes; sc.prims = a_prims; sc.normals = a_normals;
+// kernels that may run the stack walkers take the pair records the same way (render_kernel.hpp: DPairs)
+#define YD_SCENE_PARAMS_PAIRS YD_SCENE_PARAMS, const float4 *__restrict__ a_pairs, int stack_levels
 
 // ---- ray regrouping inside a workgroup of WPB waves ----------------------------------------------
 // Barrier whose fences cover LDS only: a full __syncthreads() fences global memory too, which makes every later
@@ -1022,11 +1025,11 @@ __global__ __launch_bounds__(1024) void k_sort_scatter(SParams sp) {
 #define YD_LEVEL_WAVES 1
 template <int MODE, bool STATS>
 __global__ __launch_bounds__(64 * YD_LEVEL_WAVES) __attribute__((amdgpu_waves_per_eu(YAHR_WAVES_LANE, 8)))
-void k_stream_level(DScene sc_in, YD_SCENE_PARAMS, SParams sp, unsigned long long *__restrict__ ctr) {
+void k_stream_level(DScene sc_in, YD_SCENE_PARAMS_PAIRS, SParams sp, unsigned long long *__restrict__ ctr) {
   extern __shared__ int trav_stack[];                                  // stack walkers: stack_levels x 64 entries per wavefront
   YD_SCENE_BIND
   const int lane = threadIdx.x & 63;
-  int *stk = trav_stack + (size_t)(threadIdx.x >> 6) * 64 * (size_t)sc.stack_levels + lane;
+  int *stk = trav_stack + (size_t)(threadIdx.x >> 6) * 64 * (size_t)stack_levels + lane;
   const int k = sp.level, in = k & 1;
   const unsigned n_in = sp.count[k];
   const unsigned chunk = blockIdx.x * YD_LEVEL_WAVES + (threadIdx.x >> 6);
@@ -1063,7 +1066,7 @@ void k_stream_level(DScene sc_in, YD_SCENE_PARAMS, SParams sp, unsigned long lon
     Hit hit;
     // the paths of a wavefront are neighbours in space (Morton order) and a shadow ray's direction follows from its
     // origin: coherent rays, so the adaptive walker stays a packet for them (1 M triangles: 38.3 -> 37.2 ms per frame)
-    traverse<MODE, STATS>(sc, active, true, true, qo, qdir, qt, hit, c, stk);
+    traverse<MODE, STATS>(sc, active, true, true, qo, qdir, qt, hit, c, stk, a_pairs);
     if (valid) direct = direct + ((active && hit.prim < 0) ? cv : vof(0.0f));   // sum = foldl (+) 0, light order
   }
   const V3 r = rd - scale(2.0f * dot(rd, n), n);                       // reflectionDir, Integrators.hs:46-47
@@ -1078,7 +1081,7 @@ void k_stream_level(DScene sc_in, YD_SCENE_PARAMS, SParams sp, unsigned long lon
     const V3 ro2 = x + scale(0.001f, r);                               // Integrators.hs:41-43
     if (STATS) c.reflection += lanes(valid);
     Hit hit;
-    traverse<MODE, STATS>(sc, valid, false, false, ro2, r, 1e6f, hit, c, stk);
+    traverse<MODE, STATS>(sc, valid, false, false, ro2, r, 1e6f, hit, c, stk, a_pairs);
     const bool alive = valid && hit.prim >= 0;
     if (STATS) c.shaded += lanes(alive);
     V3 x2 = vof(0.0f), n2 = vof(0.0f), dpdu2 = vof(0.0f);
@@ -1141,7 +1144,7 @@ __global__ __launch_bounds__(256) void k_stream_resolve_lanes(RParams rp, SParam
 
 // ---- diagnostic kernels: device functions on arbitrary rays (KAT checks on the GPU) -----------------
 template <int MODE>
-__global__ __launch_bounds__(64) void k_trace(DScene sc_in, YD_SCENE_PARAMS, int n, const float *__restrict__ rays,
+__global__ __launch_bounds__(64) void k_trace(DScene sc_in, YD_SCENE_PARAMS_PAIRS, int n, const float *__restrict__ rays,
                                               int any_hit, int *__restrict__ prim_out, float *__restrict__ t_out) {
   extern __shared__ int trav_stack[];
   YD_SCENE_BIND
@@ -1150,7 +1153,7 @@ __global__ __launch_bounds__(64) void k_trace(DScene sc_in, YD_SCENE_PARAMS, int
   V3 o = vof(0.0f), d = v3(0, 0, 1); float tmax = 0.0f;
   if (valid) { const float *p = rays + 7 * (size_t)i; o = v3(p[0], p[1], p[2]); d = v3(p[3], p[4], p[5]); tmax = p[6]; }
   Hit h; Counters c = {};
-  traverse<MODE, false>(sc, valid, any_hit != 0, false, o, d, tmax, h, c, trav_stack + threadIdx.x);
+  traverse<MODE, false>(sc, valid, any_hit != 0, false, o, d, tmax, h, c, trav_stack + threadIdx.x, a_pairs);
   if (valid) {
     prim_out[i] = h.prim >= 0 ? __float_as_int(sc.prims[3 * (size_t)h.prim + 2].w) : -1;
     if (t_out) t_out[i] = h.t;
@@ -1193,8 +1196,8 @@ static hipError_t launch_render_mode(const DScene &sc, const RParams &rp, int n_
   // per-level (w_k, D_k) stack of every thread, then (WPB > 1) the exchange area of traverse_block / block_any
   const size_t lds_bytes = ((size_t)(sc.depth > 0 ? sc.depth : 1) * 6 * 64 * WPB +
                             (WPB > 1 ? 12 * 64 * WPB + 2 * WPB : 0)) * sizeof(float);
-  if (stats) hipLaunchKernelGGL((k_render<MODE, true, WPB>), dim3(n_blocks), dim3(64 * WPB), lds_bytes, st, sc, sc.nodes, sc.prims, sc.normals, sc.pairs, rp, out, ctr);
-  else hipLaunchKernelGGL((k_render<MODE, false, WPB>), dim3(n_blocks), dim3(64 * WPB), lds_bytes, st, sc, sc.nodes, sc.prims, sc.normals, sc.pairs, rp, out, ctr);
+  if (stats) hipLaunchKernelGGL((k_render<MODE, true, WPB>), dim3(n_blocks), dim3(64 * WPB), lds_bytes, st, sc, sc.nodes, sc.prims, sc.normals, rp, out, ctr);
+  else hipLaunchKernelGGL((k_render<MODE, false, WPB>), dim3(n_blocks), dim3(64 * WPB), lds_bytes, st, sc, sc.nodes, sc.prims, sc.normals, rp, out, ctr);
   return hipGetLastError();
 }
 
@@ -1215,36 +1218,36 @@ hipError_t launch_render(const DScene &sc, const RParams &rp, int mode, bool reg
 }
 
 template <int MODE>
-static void launch_stream_levels(const DScene &sc, SParams sp, int n_level_blocks, unsigned long long *ctr, bool stats,
+static void launch_stream_levels(const DScene &sc, const DPairs &dp, SParams sp, int n_level_blocks, unsigned long long *ctr, bool stats,
                                  hipStream_t st) {
   const unsigned sort_blocks = (sp.capacity + 1023u) / 1024u;
   // the stack walkers keep a per-lane stack of pending right siblings in LDS: stack_levels x 64 entries per wavefront
   size_t lds = (MODE == TRAV_STACK || MODE == TRAV_ADAPT_STACK || MODE == TRAV_ORDERED)
-                         ? (size_t)sc.stack_levels * 64 * YD_LEVEL_WAVES * sizeof(int) : 0;
+                         ? (size_t)dp.stack_levels * 64 * YD_LEVEL_WAVES * sizeof(int) : 0;
   if (const char *e = getenv("YAHR_DEBUG_LDS")) lds = (size_t)atoi(e);     // occupancy experiments
   for (int k = 0; k < sc.depth; ++k) {
     sp.level = k; sp.last = (k == sc.depth - 1) ? 1 : 0;
     hipLaunchKernelGGL(k_sort_scan, dim3(YD_SORT_CELLS / 1024u), dim3(1024), 0, st, sp);
     hipLaunchKernelGGL(k_sort_scatter, dim3(sort_blocks), dim3(1024), 0, st, sp);
-    if (stats) hipLaunchKernelGGL((k_stream_level<MODE, true>), dim3(n_level_blocks), dim3(64 * YD_LEVEL_WAVES), lds, st, sc, sc.nodes, sc.prims, sc.normals, sc.pairs, sp, ctr);
-    else hipLaunchKernelGGL((k_stream_level<MODE, false>), dim3(n_level_blocks), dim3(64 * YD_LEVEL_WAVES), lds, st, sc, sc.nodes, sc.prims, sc.normals, sc.pairs, sp, ctr);
+    if (stats) hipLaunchKernelGGL((k_stream_level<MODE, true>), dim3(n_level_blocks), dim3(64 * YD_LEVEL_WAVES), lds, st, sc, sc.nodes, sc.prims, sc.normals, dp.pairs, dp.stack_levels, sp, ctr);
+    else hipLaunchKernelGGL((k_stream_level<MODE, false>), dim3(n_level_blocks), dim3(64 * YD_LEVEL_WAVES), lds, st, sc, sc.nodes, sc.prims, sc.normals, dp.pairs, dp.stack_levels, sp, ctr);
   }
 }
 
-hipError_t launch_stream_pass(const DScene &sc, const RParams &rp, SParams sp, int secondary_mode, int n_blocks, float *out,
+hipError_t launch_stream_pass(const DScene &sc, const DPairs &dp, const RParams &rp, SParams sp, int secondary_mode, int n_blocks, float *out,
                               unsigned long long *ctr, bool stats, hipStream_t st) {
-  if (stats) hipLaunchKernelGGL((k_stream_primary<true>), dim3(n_blocks), dim3(64), 0, st, sc, sc.nodes, sc.prims, sc.normals, sc.pairs, rp, sp, ctr);
-  else hipLaunchKernelGGL((k_stream_primary<false>), dim3(n_blocks), dim3(64), 0, st, sc, sc.nodes, sc.prims, sc.normals, sc.pairs, rp, sp, ctr);
+  if (stats) hipLaunchKernelGGL((k_stream_primary<true>), dim3(n_blocks), dim3(64), 0, st, sc, sc.nodes, sc.prims, sc.normals, rp, sp, ctr);
+  else hipLaunchKernelGGL((k_stream_primary<false>), dim3(n_blocks), dim3(64), 0, st, sc, sc.nodes, sc.prims, sc.normals, rp, sp, ctr);
   // the level launches cover the queue's capacity; wavefronts beyond the queue's length exit at once
   const int n_level_blocks = (int)((sp.capacity + 64u * YD_LEVEL_WAVES - 1u) / (64u * YD_LEVEL_WAVES));
   // (a scene without pair records runs the stack modes too: they fall back to the skip-link lane walker per wavefront)
   switch (secondary_mode) {
-    case TRAV_LANE: launch_stream_levels<TRAV_LANE>(sc, sp, n_level_blocks, ctr, stats, st); break;
-    case TRAV_PACKET: launch_stream_levels<TRAV_PACKET>(sc, sp, n_level_blocks, ctr, stats, st); break;
-    case TRAV_STACK: launch_stream_levels<TRAV_STACK>(sc, sp, n_level_blocks, ctr, stats, st); break;
-    case TRAV_ADAPT_STACK: launch_stream_levels<TRAV_ADAPT_STACK>(sc, sp, n_level_blocks, ctr, stats, st); break;
-    case TRAV_ORDERED: launch_stream_levels<TRAV_ORDERED>(sc, sp, n_level_blocks, ctr, stats, st); break;
-    default: launch_stream_levels<TRAV_ADAPTIVE>(sc, sp, n_level_blocks, ctr, stats, st); break;
+    case TRAV_LANE: launch_stream_levels<TRAV_LANE>(sc, dp, sp, n_level_blocks, ctr, stats, st); break;
+    case TRAV_PACKET: launch_stream_levels<TRAV_PACKET>(sc, dp, sp, n_level_blocks, ctr, stats, st); break;
+    case TRAV_STACK: launch_stream_levels<TRAV_STACK>(sc, dp, sp, n_level_blocks, ctr, stats, st); break;
+    case TRAV_ADAPT_STACK: launch_stream_levels<TRAV_ADAPT_STACK>(sc, dp, sp, n_level_blocks, ctr, stats, st); break;
+    case TRAV_ORDERED: launch_stream_levels<TRAV_ORDERED>(sc, dp, sp, n_level_blocks, ctr, stats, st); break;
+    default: launch_stream_levels<TRAV_ADAPTIVE>(sc, dp, sp, n_level_blocks, ctr, stats, st); break;
   }
   const size_t n_px = (size_t)sp.band_rows * (size_t)rp.width;
   int spp_log2 = 0;
@@ -1257,11 +1260,11 @@ hipError_t launch_stream_pass(const DScene &sc, const RParams &rp, SParams sp, i
   return hipGetLastError();
 }
 
-hipError_t launch_trace(const DScene &sc, int mode, int n, const float *rays, int any_hit, int *prim_out,
+hipError_t launch_trace(const DScene &sc, const DPairs &dp, int mode, int n, const float *rays, int any_hit, int *prim_out,
                         float *t_out, hipStream_t st) {
   const int nb = (n + 63) / 64;
-  const size_t lds = (size_t)sc.stack_levels * 64 * sizeof(int);
-#define YD_TRACE(M, L) hipLaunchKernelGGL((k_trace<M>), dim3(nb), dim3(64), L, st, sc, sc.nodes, sc.prims, sc.normals, sc.pairs, n, rays, any_hit, prim_out, t_out)
+  const size_t lds = (size_t)dp.stack_levels * 64 * sizeof(int);
+#define YD_TRACE(M, L) hipLaunchKernelGGL((k_trace<M>), dim3(nb), dim3(64), L, st, sc, sc.nodes, sc.prims, sc.normals, dp.pairs, dp.stack_levels, n, rays, any_hit, prim_out, t_out)
   switch (mode) {
     case TRAV_LANE: YD_TRACE(TRAV_LANE, 0); break;
     case TRAV_STACK: YD_TRACE(TRAV_STACK, lds); break;
@@ -1278,9 +1281,9 @@ hipError_t launch_radiance(const DScene &sc, int mode, int n, const float *rays,
                            unsigned long long *ctr, hipStream_t st) {
   const int nb = (n + 63) / 64;
   const size_t lds_bytes = (size_t)(sc.depth > 0 ? sc.depth : 1) * 6 * 64 * sizeof(float);
-  if (mode == TRAV_LANE) hipLaunchKernelGGL((k_radiance<TRAV_LANE>), dim3(nb), dim3(64), lds_bytes, st, sc, sc.nodes, sc.prims, sc.normals, sc.pairs, n, rays, rgb, ctr);
-  else if (mode == TRAV_PACKET) hipLaunchKernelGGL((k_radiance<TRAV_PACKET>), dim3(nb), dim3(64), lds_bytes, st, sc, sc.nodes, sc.prims, sc.normals, sc.pairs, n, rays, rgb, ctr);
-  else hipLaunchKernelGGL((k_radiance<TRAV_ADAPTIVE>), dim3(nb), dim3(64), lds_bytes, st, sc, sc.nodes, sc.prims, sc.normals, sc.pairs, n, rays, rgb, ctr);
+  if (mode == TRAV_LANE) hipLaunchKernelGGL((k_radiance<TRAV_LANE>), dim3(nb), dim3(64), lds_bytes, st, sc, sc.nodes, sc.prims, sc.normals, n, rays, rgb, ctr);
+  else if (mode == TRAV_PACKET) hipLaunchKernelGGL((k_radiance<TRAV_PACKET>), dim3(nb), dim3(64), lds_bytes, st, sc, sc.nodes, sc.prims, sc.normals, n, rays, rgb, ctr);
+  else hipLaunchKernelGGL((k_radiance<TRAV_ADAPTIVE>), dim3(nb), dim3(64), lds_bytes, st, sc, sc.nodes, sc.prims, sc.normals, n, rays, rgb, ctr);
   return hipGetLastError();
 }
 

@@ -25,12 +25,16 @@ struct DScene {
   int n_nodes, n_prims, n_mats, n_lights;
   int depth;
   int boxes_finite;        // every node box has finite lo <= hi: enables the NaN-free slab form
-  // Child-pair records for the stack walker (render_kernel.hip: stack_loop): interior node of rank k (k-th interior node
-  // in DFS order; the root is 0) owns 64 B = the records of its LEFT and RIGHT child side by side, 4 float4 words.  A child
-  // record is the child's yahr_node with other links: leaf {lo, count, hi, first primitive} as in `nodes`; interior
-  // {lo, rank of the child, hi, -1 - DFS index of the child}.  NULL when the scene has none (root is a leaf, a box is not
-  // finite, or a node's box is not exactly the join of its children's).  stack_levels = depth of the deepest node = entries
-  // of the per-lane LDS stack of pending right siblings.
+};
+
+// Child-pair records for the stack walkers (render_kernel.hip: stack_loop), handed to the kernels that may run them (kept
+// out of DScene: the packet kernels' register allocation is sensitive to the size of their argument block).  Interior
+// node of rank k (k-th interior node in DFS order; the root is 0) owns 64 B = the records of its LEFT and RIGHT child side
+// by side, 4 float4 words.  A child record is the child's yahr_node with other links: leaf {lo, count, hi, first primitive}
+// as in `nodes`; interior {lo, rank of the child, hi, -1 - DFS index of the child}.  pairs == NULL when the scene has none
+// (root is a leaf, a box is not finite, or a node's box is not exactly the join of its children's).  stack_levels = depth
+// of the deepest node = entries of the per-lane LDS stack of pending right siblings.
+struct DPairs {
   const float4 *pairs;
   int stack_levels;
 };
@@ -101,12 +105,12 @@ enum { CTR_PRIMARY = 0, CTR_REFLECTION, CTR_SHADOW, CTR_SHADED, CTR_BAD_MAT,
 namespace yahr_dev {
 hipError_t launch_render(const DScene &sc, const RParams &rp, int mode, bool regroup, int n_blocks, float *out,
                          unsigned long long *ctr, bool stats, hipStream_t st);
-hipError_t launch_trace(const DScene &sc, int mode, int n, const float *rays, int any_hit, int *prim_out,
+hipError_t launch_trace(const DScene &sc, const DPairs &dp, int mode, int n, const float *rays, int any_hit, int *prim_out,
                         float *t_out, hipStream_t st);
 hipError_t launch_radiance(const DScene &sc, int mode, int n, const float *rays, float *rgb,
                            unsigned long long *ctr, hipStream_t st);
 hipError_t launch_camera_rays(const DScene &sc, int n, const float *uv, float *rays, hipStream_t st);
 // stream form: one pass = primary + depth level launches + resolve, all on `st`; sp.count must be zeroed by the caller
-hipError_t launch_stream_pass(const DScene &sc, const RParams &rp, SParams sp, int secondary_mode, int n_blocks, float *out,
+hipError_t launch_stream_pass(const DScene &sc, const DPairs &dp, const RParams &rp, SParams sp, int secondary_mode, int n_blocks, float *out,
                               unsigned long long *ctr, bool stats, hipStream_t st);
 }  // namespace yahr_dev

@@ -95,11 +95,36 @@ def test_reference_e2e_scene(gpu):
     assert outside_tol(img, ref) == 0 and img.shape == (10, 10, 3)
 
 
-@pytest.mark.parametrize("depth", [0, 1, 2, 4, 7])
+@pytest.mark.parametrize("depth", [0, 1, 2, 4, 5, 7, 43, 64, 300])
 def test_recursion_depths(gpu, depth):
+    """recursionDepth is an unbounded Int upstream (Integrators.hs:18-20).  Up to 4 the (w_k, D_k) stack of the fused
+    kernels lives in LDS; beyond that three levels do and the rest sit in a global array (43 is where the all-LDS layout
+    stopped launching, 300 is past the 8-bit level count the stream form once had)."""
     img, ref = assert_parity(scenes.scene_fixed(96, 64).with_(depth=depth))
     if depth == 0:
         assert not img.any()                                             # vcast 0 _ = 0
+
+
+def test_deep_recursion_in_several_launches(gpu, monkeypatch):
+    """the level spill of a deep scene is cut to a memory budget: the grid then runs as several launches (here 24 KiB
+    per launch = a handful of workgroups), frame batches included; same image, same counters"""
+    d = scenes.scene_fixed(96, 64).with_(depth=9)
+    ref, ost = oracle_render(d)
+    scene = d.to_scene().build()
+    ctx = yahr_amd.Context(scene, 0)
+    whole = ctx.render(traverse=yahr_amd.TRAVERSE_PACKET).cpu().numpy()
+    monkeypatch.setenv("YAHR_SPILL_BUDGET_KB", "24")
+    for m in FUSED_MODES:
+        img = ctx.render(traverse=m, collect_stats=True).cpu().numpy()
+        st = ctx.stats()
+        assert np.array_equal(bits(img), bits(whole)) and outside_tol(img, ref) == 0, m
+        for k in ("primary_rays", "reflection_rays", "shadow_rays", "shaded_hits", "box_tests", "tri_tests", "sphere_tests"):
+            assert st[k] == ost[k], (k, m)
+    batch = ctx.render(traverse=yahr_amd.TRAVERSE_PACKET, frames=3).cpu().numpy()
+    assert all(np.array_equal(bits(batch[f]), bits(whole)) for f in range(3))
+    rays = np.stack([OracleScene.from_desc(d).build().camera_ray(u, v) for u in range(0, 96, 12) for v in range(0, 64, 8)])
+    assert outside_tol(ctx.radiance(rays, yahr_amd.TRAVERSE_PACKET)[None], np.stack([OracleScene.from_desc(d).build().radiance(r) for r in rays])[None]) == 0
+    ctx.close()
 
 
 @pytest.mark.parametrize("split", ["Midpoint", "SurfaceAreaHeuristic"])

@@ -42,13 +42,15 @@ def meta(asm, prefix):
     return {k: int(v) for k, v in re.findall(r"\.(\w+):\s+(\d+)", m.group(1))}
 
 
-# k_render<MODE, STATS, WPB>: MODE 1 lane / 2 packet / 3 adaptive; WPB waves per workgroup (4 = ray regrouping)
-PACKET_FAST = "_Z8k_renderILi2ELb0ELi1EE"
-LANE_FAST = "_Z8k_renderILi1ELb0ELi1EE"
-ADAPTIVE_FAST = "_Z8k_renderILi3ELb0ELi1EE"
-PACKET_STATS = "_Z8k_renderILi2ELb1ELi1EE"
-PACKET_REGROUP = "_Z8k_renderILi2ELb0ELi4EE"
-ADAPTIVE_REGROUP = "_Z8k_renderILi3ELb0ELi4EE"
+# k_render<MODE, STATS, WPB, DEEP>: MODE 1 lane / 2 packet / 3 adaptive; WPB waves per workgroup (4 = ray regrouping);
+# DEEP = recursion depth > 4, upper levels of the radiance stack in global memory
+PACKET_FAST = "_Z8k_renderILi2ELb0ELi1ELb0EE"
+LANE_FAST = "_Z8k_renderILi1ELb0ELi1ELb0EE"
+ADAPTIVE_FAST = "_Z8k_renderILi3ELb0ELi1ELb0EE"
+PACKET_STATS = "_Z8k_renderILi2ELb1ELi1ELb0EE"
+PACKET_REGROUP = "_Z8k_renderILi2ELb0ELi4ELb0EE"
+ADAPTIVE_REGROUP = "_Z8k_renderILi3ELb0ELi4ELb0EE"
+PACKET_DEEP = "_Z8k_renderILi2ELb0ELi1ELb1EE"
 
 
 def test_packet_walker_uses_scalar_loads(asm):
@@ -64,7 +66,8 @@ def test_packet_walker_uses_scalar_loads(asm):
     assert len(re.findall(r"global_load_dword", lane)) >= 10      # the lane walker gathers per lane, by design
     # the record arrays are `const __restrict__` kernel arguments, so counters (atomics, clock reads) and the
     # workgroup barriers of the regrouping variants do not cost the packet walker its scalar loads either
-    for k in (PACKET_STATS, PACKET_REGROUP, ADAPTIVE_REGROUP):
+    # ... nor do the stores of the deep-scene variant (levels of the radiance stack spilled to global memory mid-loop)
+    for k in (PACKET_STATS, PACKET_REGROUP, ADAPTIVE_REGROUP, PACKET_DEEP):
         body = kernel_body(asm, k)
         assert len(re.findall(r"s_load_dwordx8", body)) >= 5, k
     assert "s_barrier" in kernel_body(asm, PACKET_REGROUP)

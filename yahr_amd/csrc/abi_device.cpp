@@ -36,6 +36,8 @@ struct yahr_ctx {
   int4 *d_windows = nullptr; int n_windows = 0, n_chunks = 0, windows_w = 0, windows_h = 0;
   // wavefront ("stream") form: path queues, per-level results, queue lengths (allocated on first use, grown on demand)
   void *d_stream = nullptr; size_t stream_bytes = 0;
+  // fused kernels, scenes deeper than YD_LDS_LEVELS: the upper levels of the radiance stack (allocated on first use)
+  void *d_spill = nullptr; size_t spill_bytes = 0;
   unsigned *d_qcount = nullptr; int qcount_n = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
@@ -323,7 +325,7 @@ void yahr_ctx_destroy(yahr_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipFree(c->d_nodes); (void)hipFree(c->d_prims); (void)hipFree(c->d_normals); (void)hipFree(c->d_mats);
   (void)hipFree(c->d_lights); (void)hipFree(c->d_ctr); (void)hipFree(c->d_windows); (void)hipFree(c->d_cold); (void)hipFree(c->d_pairs);
-  (void)hipFree(c->d_cams); (void)hipFree(c->d_row_order); (void)hipFree(c->d_stream); (void)hipFree(c->d_qcount);
+  (void)hipFree(c->d_cams); (void)hipFree(c->d_row_order); (void)hipFree(c->d_stream); (void)hipFree(c->d_qcount); (void)hipFree(c->d_spill);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   delete c;
@@ -367,7 +369,7 @@ static int ensure_windows(yahr_ctx *c, int n_batches) {
 // ---- wavefront ("stream") form ------------------------------------------------------------------------
 // bytes per sample of a pass: two ping-pong path queues of 64 B, (w_k, D_k) of every level, the level count, and the
 // Morton cell + sorted position of a queue entry (4 B each); the cell histogram of the sort comes on top once
-static size_t stream_bytes_per_sample(int depth) { return 2 * 64 + (size_t)depth * 32 + 1 + 12; }
+static size_t stream_bytes_per_sample(int depth) { return 2 * 64 + (size_t)depth * 32 + 2 + 12; }
 static size_t stream_fixed_bytes(int depth) { return sizeof(unsigned) * YD_SORT_CELLS * (size_t)(depth + 2) + 4096; }
 
 // The image is processed in BANDS of whole tile rows so that the queues of one pass stay below a budget: an eighth of
@@ -420,7 +422,7 @@ static int ensure_stream(yahr_ctx *c, size_t n_samples, int depth, SParams &sp) 
   sp.perm = (unsigned *)p; p += 4 * n_samples;
   sp.hist = (unsigned *)p; p += sizeof(unsigned) * YD_SORT_CELLS * (size_t)(depth + 1);
   sp.start = (unsigned *)p; p += sizeof(unsigned) * YD_SORT_CELLS;
-  sp.levels = (unsigned char *)p;
+  sp.levels = (unsigned short *)p;
   sp.count = c->d_qcount;
   sp.capacity = (unsigned)n_samples;
   return YAHR_OK;
@@ -507,7 +509,8 @@ int yahr_ctx_render(yahr_ctx *c, int32_t row0, int32_t row1, const yahr_render_o
   if (mode == TRAV_STREAM) {
     // per frame of the batch and per band of rows: camera-ray launch, one launch per recursion level, resolve
     tile_h = (64 >> rp.sil_log2) >> rp.pw_log2;
-    const bool can = rp.tile_mode == 0 && !regroup && rp.row_order == nullptr && !rp.xcd_swizzle;
+    // (the per-sample level count is 16 bits wide)
+    const bool can = rp.tile_mode == 0 && !regroup && rp.row_order == nullptr && !rp.xcd_swizzle && c->ds.depth <= 65535;
     if (can) band_rows = stream_band_rows(c, rp.n_local_rows, tile_h, o.spp, c->ds.depth);
     if (band_rows == 0) {
       if (o.traverse == YAHR_TRAVERSE_STREAM || o.traverse >= YAHR_TRAVERSE_STACK) {
@@ -557,7 +560,35 @@ int yahr_ctx_render(yahr_ctx *c, int32_t row0, int32_t row1, const yahr_render_o
       }
     }
   } else {
-    HIP_TRY(yahr_dev::launch_render(c->ds, rp, mode, regroup, n_blocks, d_rgb, c->d_ctr, o.collect_stats != 0, st));
+    // recursionDepth is an unbounded Int upstream (Integrators.hs:18-20): the first YD_LDS_LEVELS levels of the (w_k, D_k)
+    // stack live in LDS, the levels above them in a global array with one slice per workgroup of the launch.  A grid whose
+    // slices would not fit the budget (an eighth of the free memory, at most 8 GiB) is cut into several launches.
+    rp.lds_levels = c->ds.depth <= YD_LDS_DEPTH ? c->ds.depth : YD_LDS_LEVELS;
+    const size_t extra = (size_t)(c->ds.depth - rp.lds_levels);
+    if (extra > 0 && regroup) { set_error("the ray-regrouping diagnostics build keeps its level stack in LDS: recursion depth <= 4 only"); return YAHR_E_ARG; }
+    int chunk = n_blocks;
+    if (extra > 0) {
+      const size_t per_block = extra * 6 * 64 * sizeof(float);
+      size_t fr = 0, tot = 0;
+      HIP_TRY(hipMemGetInfo(&fr, &tot));
+      size_t budget = std::min((fr + c->spill_bytes) / 8, (size_t)8 << 30);
+      if (const char *e = std::getenv("YAHR_SPILL_BUDGET_KB")) { const long v = std::atol(e); if (v > 0) budget = (size_t)v << 10; }   // tests
+      budget = std::max(budget, c->spill_bytes);
+      size_t fit = budget / per_block;
+      if (fit == 0) { set_error("recursion depth too large: the level stack of one workgroup exceeds the device memory budget"); return YAHR_E_NOMEM; }
+      if (fit < (size_t)n_blocks) chunk = (int)fit;
+      const size_t need = (size_t)chunk * per_block;
+      if (need > c->spill_bytes) {
+        if (c->d_spill) { HIP_TRY(hipFree(c->d_spill)); c->d_spill = nullptr; c->spill_bytes = 0; }
+        HIP_TRY(dev_alloc(&c->d_spill, need));
+        c->spill_bytes = need;
+      }
+      rp.lvl_spill = (float *)c->d_spill;
+    }
+    for (int b0 = 0; b0 < n_blocks; b0 += chunk) {
+      rp.block0 = (unsigned)b0;
+      HIP_TRY(yahr_dev::launch_render(c->ds, rp, mode, regroup, std::min(chunk, n_blocks - b0), d_rgb, c->d_ctr, o.collect_stats != 0, st));
+    }
   }
   HIP_TRY(hipEventRecord(c->ev1, st));
   c->timed = true;
@@ -628,7 +659,11 @@ static int ray_query(yahr_ctx *c, int32_t n, const float *rays, int which, int t
                      : traverse == YAHR_TRAVERSE_ORDERED ? TRAV_ORDERED : 0;    // closest / first hit on the pair records
   if (which == 2) {
     HIP_TRY(d_f.alloc(sizeof(float) * 3 * (size_t)n));
-    HIP_TRY(yahr_dev::launch_radiance(c->ds, mode, n, d_rays.as<float>(), d_f.as<float>(), c->d_ctr, nullptr));
+    DevMem d_lvl;                                           // levels of the radiance stack beyond the LDS part
+    const int lds_levels = std::min(c->ds.depth, YD_LDS_LEVELS);
+    if (c->ds.depth > lds_levels)
+      HIP_TRY(d_lvl.alloc((size_t)((n + 63) / 64) * (size_t)(c->ds.depth - lds_levels) * 6 * 64 * sizeof(float)));
+    HIP_TRY(yahr_dev::launch_radiance(c->ds, mode, n, d_rays.as<float>(), d_f.as<float>(), c->d_ctr, d_lvl.as<float>(), lds_levels, nullptr));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(fout, d_f.p, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost));
   } else {

@@ -683,8 +683,13 @@ YD V3 material_at(const DScene &sc, int mat, V3 n, V3 dpdu, V3 wi, V3 wo) {
 //   phase 1..L   shadow probe towards light phase-1 (Lights.hs:15-24, Rays.hs:49-54); its contribution
 //                cv = |lightDir.n| @* k * intensity is formed BEFORE the probe so that only cv stays live
 //   after phase L: w_k, D_k to LDS, reflection ray (Integrators.hs:40-47)
-template <int MODE, bool STATS, int WPB>
-YD V3 radiance(const DScene &sc, bool valid, V3 ro, V3 rd, float *lds, float *xch, Counters &c, bool &bad_mat) {
+// DEEP: levels 0 .. lds_levels-1 of the (w_k, D_k) stack live in LDS, the levels above them in `spill`, this workgroup's
+// slice of a global array laid out the same way (recursionDepth is an unbounded Int upstream, Integrators.hs:18-20; LDS
+// is not).  Same values, same fold order: where a level is kept cannot change a result.  Without DEEP every level fits
+// LDS and no code for the spill exists.
+template <int MODE, bool STATS, int WPB, bool DEEP = false>
+YD V3 radiance(const DScene &sc, bool valid, V3 ro, V3 rd, float *lds, float *xch, Counters &c, bool &bad_mat,
+               float *__restrict__ spill = nullptr, int lds_levels = 0) {
   constexpr int B = 64 * WPB;                                         // threads per workgroup
   const int tid = threadIdx.x;
   bool alive = valid;
@@ -737,15 +742,27 @@ YD V3 radiance(const DScene &sc, bool valid, V3 ro, V3 rd, float *lds, float *xc
       const V3 r = rd - scale(2.0f * dot(rd, n), n);                  // reflectionDir, Integrators.hs:46-47
       const V3 f_r = material_at(sc, mat, n, dpdu, r, vneg(rd));
       const V3 w = scale(dot(n, r), f_r);
-      float *slot = lds + (size_t)k * 6 * B + tid;
-      slot[0] = w.x; slot[B] = w.y; slot[2 * B] = w.z;
-      slot[3 * B] = direct.x; slot[4 * B] = direct.y; slot[5 * B] = direct.z;
+      if (!DEEP || k < lds_levels) {                                  // wave-uniform
+        float *slot = lds + (size_t)k * 6 * B + tid;
+        slot[0] = w.x; slot[B] = w.y; slot[2 * B] = w.z;
+        slot[3 * B] = direct.x; slot[4 * B] = direct.y; slot[5 * B] = direct.z;
+      } else {
+        float *slot = spill + (size_t)(k - lds_levels) * 6 * B + tid;
+        slot[0] = w.x; slot[B] = w.y; slot[2 * B] = w.z;
+        slot[3 * B] = direct.x; slot[4 * B] = direct.y; slot[5 * B] = direct.z;
+      }
       levels = k + 1;
       ro = x + scale(0.001f, r); rd = r;                              // Integrators.hs:41-43
     }
   }
   V3 v = vof(0.0f);                                                   // vcast 0 _ = 0 / miss = 0
-  for (int k = levels - 1; k >= 0; --k) {
+  if (DEEP)
+    for (int k = levels - 1; k >= lds_levels; --k) {                  // (per-lane trip count: the lane's own levels)
+      const float *slot = spill + (size_t)(k - lds_levels) * 6 * B + tid;
+      V3 w = v3(slot[0], slot[B], slot[2 * B]), d = v3(slot[3 * B], slot[4 * B], slot[5 * B]);
+      v = (w * v) + d;
+    }
+  for (int k = (DEEP && levels > lds_levels ? lds_levels : levels) - 1; k >= 0; --k) {
     const float *slot = lds + (size_t)k * 6 * B + tid;
     V3 w = v3(slot[0], slot[B], slot[2 * B]), d = v3(slot[3 * B], slot[4 * B], slot[5 * B]);
     v = (w * v) + d;
@@ -800,19 +817,22 @@ YD void wave_tile_pixel(const RParams &rp, int tile, int lane, int &u, int &gv, 
 // walked 64 pixels at a time, u-major like the reference.  WPB = 1: one wave per workgroup.  WPB = 4: a
 // workgroup owns 2x2 tiles (or 4 consecutive window chunks) and regroups its rays before every traversal
 // (traverse_block).
-template <int MODE, bool STATS, int WPB>
+template <int MODE, bool STATS, int WPB, bool DEEP = false>
 __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(MODE == TRAV_PACKET ? YAHR_WAVES : YAHR_WAVES_LANE, 8)))
 void k_render(DScene sc_in, YD_SCENE_PARAMS, RParams rp, float *__restrict__ out, unsigned long long *__restrict__ ctr) {
   extern __shared__ float lds[];
   YD_SCENE_BIND
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float *xch = lds + (size_t)(sc.depth > 0 ? sc.depth : 1) * 6 * 64 * WPB;   // exchange area (WPB > 1 only)
+  float *xch = lds + (size_t)(sc.depth > 0 ? sc.depth : 1) * 6 * 64 * WPB;   // exchange area (WPB > 1 only; never DEEP)
+  // DEEP: this workgroup's slice of the level spill (levels beyond the LDS part; only ever touched by such levels)
+  float *spill = DEEP ? rp.lvl_spill + (size_t)blockIdx.x * (size_t)(sc.depth - rp.lds_levels) * (6 * 64 * WPB) : nullptr;
   Counters c = {};
   bool bad_mat = false;
   const unsigned long long t_start = STATS ? clock64() : 0ULL;
   // frame batch: the same tile of every frame of the batch sits next to each other in dispatch order
-  const int frame = rp.frames > 1 ? (int)(blockIdx.x % (unsigned)rp.frames) : 0;
-  const int unit = rp.frames > 1 ? (int)(blockIdx.x / (unsigned)rp.frames) : (int)blockIdx.x;
+  const unsigned bid = DEEP ? blockIdx.x + rp.block0 : blockIdx.x;   // (DEEP: a launch may be one chunk of a grid)
+  const int frame = rp.frames > 1 ? (int)(bid % (unsigned)rp.frames) : 0;
+  const int unit = rp.frames > 1 ? (int)(bid / (unsigned)rp.frames) : (int)bid;
   int tile = unit;
   if (WPB == 1) {
     if (rp.tile_mode == 0 && rp.xcd_swizzle) {         // diagnostics: contiguous band of tiles per XCD
@@ -858,12 +878,17 @@ void k_render(DScene sc_in, YD_SCENE_PARAMS, RParams rp, float *__restrict__ out
     if (rp.spp > 1) sample_offset(u, gv, s0 + j0, rp.n_strata, rp.seed, du, dv);
     V3 ro, rd;
     camera_ray(cam, (float)u + du, (float)gv + dv, ro, rd);
-    const V3 v = radiance<MODE, STATS, WPB>(sc, valid, ro, rd, lds, xch, c, bad_mat);
+    const V3 v = radiance<MODE, STATS, WPB, DEEP>(sc, valid, ro, rd, lds, xch, c, bad_mat, spill, rp.lds_levels);
     if (rp.sil_log2 == 0) {
       acc = (rp.spp > 1) ? acc + v : v;
     } else {
       float *park = lds;                               // the radiance stack of this wave is free again
       park[lane] = v.x; park[64 + lane] = v.y; park[128 + lane] = v.z;
+      // the pixel's first lane reads what the OTHER lanes of its wavefront stored: order the LDS accesses explicitly
+      // (the DS unit serves one wavefront's operations in order; this keeps the compiler from moving them, too)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
       if (j0 == 0)
         for (int k = 0; k < sw; ++k) acc = acc + v3(park[lane + k], park[64 + lane + k], park[128 + lane + k]);
     }
@@ -1075,7 +1100,7 @@ void k_stream_level(DScene sc_in, YD_SCENE_PARAMS_PAIRS, SParams sp, unsigned lo
   if (valid) {
     sp.lev[(size_t)(2 * k) * sp.capacity + (unsigned)sid] = make_float4(w.x, w.y, w.z, 0.0f);
     sp.lev[(size_t)(2 * k + 1) * sp.capacity + (unsigned)sid] = make_float4(direct.x, direct.y, direct.z, 0.0f);
-    sp.levels[sid] = (unsigned char)(k + 1);
+    sp.levels[sid] = (unsigned short)(k + 1);
   }
   if (!sp.last) {
     const V3 ro2 = x + scale(0.001f, r);                               // Integrators.hs:41-43
@@ -1163,7 +1188,8 @@ __global__ __launch_bounds__(64) void k_trace(DScene sc_in, YD_SCENE_PARAMS_PAIR
 // radiance of arbitrary rays; tMax of the given ray is ignored (the integrator casts with 1e6, like vcast)
 template <int MODE>
 __global__ __launch_bounds__(64) void k_radiance(DScene sc_in, YD_SCENE_PARAMS, int n, const float *__restrict__ rays,
-                                                 float *__restrict__ rgb, unsigned long long *__restrict__ ctr) {
+                                                 float *__restrict__ rgb, unsigned long long *__restrict__ ctr,
+                                                 float *__restrict__ lvl_spill, int lds_levels) {
   extern __shared__ float lds[];
   YD_SCENE_BIND
   const int i = blockIdx.x * 64 + threadIdx.x;
@@ -1172,7 +1198,8 @@ __global__ __launch_bounds__(64) void k_radiance(DScene sc_in, YD_SCENE_PARAMS, 
   if (valid) { const float *p = rays + 7 * (size_t)i; ro = v3(p[0], p[1], p[2]); rd = v3(p[3], p[4], p[5]); }
   Counters c = {};
   bool bad_mat = false;
-  V3 v = radiance<MODE, false, 1>(sc, valid, ro, rd, lds, lds, c, bad_mat);
+  V3 v = radiance<MODE, false, 1, true>(sc, valid, ro, rd, lds, lds, c, bad_mat,
+                                        lvl_spill + (size_t)blockIdx.x * (size_t)(sc.depth - lds_levels) * (6 * 64), lds_levels);
   if (valid) { rgb[3 * (size_t)i] = v.x; rgb[3 * (size_t)i + 1] = v.y; rgb[3 * (size_t)i + 2] = v.z; }
   const unsigned n_bad = lanes(bad_mat);
   if (n_bad && threadIdx.x == 0) atomicAdd(&ctr[CTR_BAD_MAT], (unsigned long long)n_bad);
@@ -1194,8 +1221,13 @@ template <int MODE, int WPB>
 static hipError_t launch_render_mode(const DScene &sc, const RParams &rp, int n_blocks, float *out,
                                      unsigned long long *ctr, bool stats, hipStream_t st) {
   // per-level (w_k, D_k) stack of every thread, then (WPB > 1) the exchange area of traverse_block / block_any
-  const size_t lds_bytes = ((size_t)(sc.depth > 0 ? sc.depth : 1) * 6 * 64 * WPB +
+  const size_t lds_bytes = ((size_t)(rp.lds_levels > 0 ? rp.lds_levels : 1) * 6 * 64 * WPB +
                             (WPB > 1 ? 12 * 64 * WPB + 2 * WPB : 0)) * sizeof(float);
+  if (WPB == 1 && rp.lds_levels < sc.depth) {            // deep scene: upper levels of the stack in rp.lvl_spill
+    if (stats) hipLaunchKernelGGL((k_render<MODE, true, 1, true>), dim3(n_blocks), dim3(64), lds_bytes, st, sc, sc.nodes, sc.prims, sc.normals, rp, out, ctr);
+    else hipLaunchKernelGGL((k_render<MODE, false, 1, true>), dim3(n_blocks), dim3(64), lds_bytes, st, sc, sc.nodes, sc.prims, sc.normals, rp, out, ctr);
+    return hipGetLastError();
+  }
   if (stats) hipLaunchKernelGGL((k_render<MODE, true, WPB>), dim3(n_blocks), dim3(64 * WPB), lds_bytes, st, sc, sc.nodes, sc.prims, sc.normals, rp, out, ctr);
   else hipLaunchKernelGGL((k_render<MODE, false, WPB>), dim3(n_blocks), dim3(64 * WPB), lds_bytes, st, sc, sc.nodes, sc.prims, sc.normals, rp, out, ctr);
   return hipGetLastError();
@@ -1278,12 +1310,12 @@ hipError_t launch_trace(const DScene &sc, const DPairs &dp, int mode, int n, con
 }
 
 hipError_t launch_radiance(const DScene &sc, int mode, int n, const float *rays, float *rgb,
-                           unsigned long long *ctr, hipStream_t st) {
+                           unsigned long long *ctr, float *lvl_spill, int lds_levels, hipStream_t st) {
   const int nb = (n + 63) / 64;
-  const size_t lds_bytes = (size_t)(sc.depth > 0 ? sc.depth : 1) * 6 * 64 * sizeof(float);
-  if (mode == TRAV_LANE) hipLaunchKernelGGL((k_radiance<TRAV_LANE>), dim3(nb), dim3(64), lds_bytes, st, sc, sc.nodes, sc.prims, sc.normals, n, rays, rgb, ctr);
-  else if (mode == TRAV_PACKET) hipLaunchKernelGGL((k_radiance<TRAV_PACKET>), dim3(nb), dim3(64), lds_bytes, st, sc, sc.nodes, sc.prims, sc.normals, n, rays, rgb, ctr);
-  else hipLaunchKernelGGL((k_radiance<TRAV_ADAPTIVE>), dim3(nb), dim3(64), lds_bytes, st, sc, sc.nodes, sc.prims, sc.normals, n, rays, rgb, ctr);
+  const size_t lds_bytes = (size_t)(lds_levels > 0 ? lds_levels : 1) * 6 * 64 * sizeof(float);
+  if (mode == TRAV_LANE) hipLaunchKernelGGL((k_radiance<TRAV_LANE>), dim3(nb), dim3(64), lds_bytes, st, sc, sc.nodes, sc.prims, sc.normals, n, rays, rgb, ctr, lvl_spill, lds_levels);
+  else if (mode == TRAV_PACKET) hipLaunchKernelGGL((k_radiance<TRAV_PACKET>), dim3(nb), dim3(64), lds_bytes, st, sc, sc.nodes, sc.prims, sc.normals, n, rays, rgb, ctr, lvl_spill, lds_levels);
+  else hipLaunchKernelGGL((k_radiance<TRAV_ADAPTIVE>), dim3(nb), dim3(64), lds_bytes, st, sc, sc.nodes, sc.prims, sc.normals, n, rays, rgb, ctr, lvl_spill, lds_levels);
   return hipGetLastError();
 }
 

@@ -59,7 +59,17 @@ struct RParams {
   size_t frame_stride;
   const DCold *cams;
   const int *row_order;    // tile_mode 0: dispatch position -> tile row (centre rows first), or NULL = natural
+  // (w_k, D_k) stack of the radiance recursion: the first lds_levels levels in LDS, the rest in lvl_spill (global,
+  // [blocks of this launch][depth - lds_levels][6][threads per block]); block0 = grid position of this launch's first
+  // block when a grid is cut into several launches so that the spill stays under a budget
+  float *lvl_spill;
+  int lds_levels;
+  unsigned block0;
 };
+// Scenes of recursion depth <= YD_LDS_DEPTH keep the whole radiance stack in LDS (1.5 KiB per level and wavefront);
+// deeper ones keep YD_LDS_LEVELS levels there (4.5 KiB: room for 32 wavefronts per CU) and the rest in the spill.
+#define YD_LDS_DEPTH 4
+#define YD_LDS_LEVELS 3
 
 // Wavefront ("stream") form of the same path, for scenes whose secondary rays are incoherent: the radiance
 // recursion (Integrators.hs:22-43) is cut at its level boundaries into separate launches, and between two launches
@@ -75,7 +85,7 @@ struct SParams {
                                            //   a = {x, sample id}  b = {n, material}  c = {dpdu, rd.x}  d = {rd.y, rd.z, -, -}
   unsigned *count;                         // [depth + 1] queue lengths
   float4 *lev;                             // [(2 k + {0: w_k, 1: D_k}) * capacity + sample id]
-  unsigned char *levels;                   // [capacity] number of levels whose ray hit something, per sample
+  unsigned short *levels;                  // [capacity] number of levels whose ray hit something, per sample (depth <= 65535)
   unsigned capacity;                       // samples of this pass = band rows x width x spp
   int tile0, lv0, band_rows;               // the pass covers the wave tiles from tile0 on = local rows [lv0, lv0 + band_rows)
   const DCold *cam;                        // camera of this pass
@@ -108,7 +118,7 @@ hipError_t launch_render(const DScene &sc, const RParams &rp, int mode, bool reg
 hipError_t launch_trace(const DScene &sc, const DPairs &dp, int mode, int n, const float *rays, int any_hit, int *prim_out,
                         float *t_out, hipStream_t st);
 hipError_t launch_radiance(const DScene &sc, int mode, int n, const float *rays, float *rgb,
-                           unsigned long long *ctr, hipStream_t st);
+                           unsigned long long *ctr, float *lvl_spill, int lds_levels, hipStream_t st);
 hipError_t launch_camera_rays(const DScene &sc, int n, const float *uv, float *rays, hipStream_t st);
 // stream form: one pass = primary + depth level launches + resolve, all on `st`; sp.count must be zeroed by the caller
 hipError_t launch_stream_pass(const DScene &sc, const DPairs &dp, const RParams &rp, SParams sp, int secondary_mode, int n_blocks, float *out,

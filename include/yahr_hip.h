@@ -35,7 +35,13 @@
 extern "C" {
 #endif
 
-#define YAHR_ABI_VERSION 1
+/* Bumped whenever a struct of this header changes size or meaning; yahr_scene.abi_version carries it and every entry point
+ * that takes a yahr_scene refuses another value, so a host compiled against an older header fails loudly instead of having
+ * a larger yahr_stats written over its smaller one.
+ *   1 -> 2: yahr_stats grew by wave_stage1_steps / wave_stage2_steps (16 bytes); yahr_render_opts.reserved[0] became
+ *           stream_walker (same size); YAHR_TRAVERSE_STACK / _HYBRID_STACK / _ORDERED; yahr_multi_submit / _wait /
+ *           _set_cameras, yahr_pinned_alloc / _free. */
+#define YAHR_ABI_VERSION 2
 
 enum {
   YAHR_OK = 0,
@@ -298,16 +304,32 @@ enum {
 };
 typedef struct yahr_multi yahr_multi;
 /* devices: n_devices indices, or NULL for 0..n_devices-1 (the first is the root).  gather: YAHR_GATHER_AUTO/RCCL/PEER;
- * naming a transport explicitly runs it even with one device (self send / self copy).  strip_rows <= 0: 8. */
+ * naming a transport explicitly runs it even with one device (self send / self copy).  strip_rows <= 0: 8.
+ * With YAHR_GATHER_PEER named explicitly a device may be listed several times (each entry gets its own resident
+ * context and streams): a rehearsal of the N-device plan on fewer GPUs. */
 int yahr_multi_create(const yahr_scene *scene, int n_devices, const int *devices, int gather, int32_t strip_rows,
                       yahr_multi **out);
-/* renders one frame (opts: spp, seed, traverse, collect_stats; sharding fields are set by the object) into the
- * HOST buffer rgb_out (height*width*3 floats); synchronous.  Repeated calls reuse contexts, buffers and communicators. */
+/* renders opts->frames frames (opts: spp, seed, traverse, collect_stats, frames; sharding fields are set by the object)
+ * into the HOST buffer rgb_out (frames*height*width*3 floats); synchronous = yahr_multi_submit + yahr_multi_wait.
+ * Repeated calls reuse contexts, buffers and communicators. */
 int yahr_multi_render(yahr_multi *m, const yahr_render_opts *opts, float *rgb_out, yahr_stats *stats_or_null);
+/* cameras of frame batches, on every device (see yahr_ctx_set_cameras); not while submissions are in flight */
+int yahr_multi_set_cameras(yahr_multi *m, int32_t n, const float *cameras);
+/* Asynchronous pair.  submit queues the renders of a frame batch on every device, the exchange step and the download
+ * into rgb_out (which must stay valid until the matching wait; memory from yahr_pinned_alloc makes the download
+ * asynchronous too) and returns; at most TWO submissions may be in flight (two buffer sets), so that the exchange and
+ * download of submission i overlap the render of submission i+1.  wait completes the OLDEST submission in flight and
+ * returns exactly its counters.  A submission that fails half way drains every stream and leaves the object unusable
+ * (every later call fails; destroy it). */
+int yahr_multi_submit(yahr_multi *m, const yahr_render_opts *opts, float *rgb_out);
+int yahr_multi_wait(yahr_multi *m, yahr_stats *stats_or_null);
+/* page-locked host memory for image buffers (hipHostMalloc); NULL on failure */
+void *yahr_pinned_alloc(size_t bytes);
+void yahr_pinned_free(void *p);
 int yahr_multi_transport(const yahr_multi *m);           /* YAHR_GATHER_RCCL / _PEER / _NONE actually in use */
 double yahr_multi_last_gather_ms(const yahr_multi *m);   /* device time of the last frame's exchange + placement */
 void yahr_multi_destroy(yahr_multi *m);
-/* one-shot: create + render + destroy */
+/* one-shot: create + render + destroy (peer-DMA transport: no communicator is set up for a single frame) */
 int yahr_render_multi(const yahr_scene *scene, int n_devices, const yahr_render_opts *opts,
                       float *rgb_out, yahr_stats *stats_or_null);
 

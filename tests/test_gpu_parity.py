@@ -87,6 +87,12 @@ def test_spheres8_direct_lighting(gpu):
     assert_parity(scenes.spheres8(480, 270))
 
 
+def test_config2_full_size_vs_oracle(gpu):
+    """BASELINE config 2 at its own size: 8 spheres + plane + 2 point lights, 1920x1080, direct lighting -- every form
+    against the oracle (which renders it in seconds), pixels within tolerance, every count equal, forms bitwise equal"""
+    assert_parity(scenes.spheres8(1920, 1080))
+
+
 def test_reference_e2e_scene(gpu):
     """the 10x10 scene of the reference's compat/test_yahr.py, text produced by the reference's serialiser"""
     scene = yahr_amd.Scene.load(os.path.join(HERE, "golden", "test_yahr_scene.yahr")).build()
@@ -782,6 +788,9 @@ def test_error_paths_do_not_leak_device_memory(gpu):
     ctx = yahr_amd.Context(scene, 0)                                    # warm-up: the runtime's own lazy allocations
     ctx.trace(rays[:64]); ctx.radiance(rays[:64]); ctx.camera_rays(uv[:64]); ctx.render().cpu()
     ctx.close()
+    m = yahr_amd.MultiContext(scene, 2, devices=[0, 0], gather=yahr_amd.GATHER_PEER)     # (streams, events, pinned pools)
+    m.render(frames=2)
+    m.close()
     free0 = free_now()
     try:
         for nth in range(1, 9):                                         # nodes, prims, normals, mats, lights, counters, cold, pairs
@@ -806,6 +815,25 @@ def test_error_paths_do_not_leak_device_memory(gpu):
         with pytest.raises(yahr_amd.YahrError):
             yahr_amd.render_image(scene)
         assert abs(free_now() - free1) <= slack
+        # yahr_multi: its contexts (9 allocations each) and its buffer sets go through the same allocator
+        for nth in list(range(1, 20, 3)) + [19, 20, 21, 22]:
+            L.yahr_debug_fail_alloc(nth)
+            with pytest.raises(yahr_amd.YahrError) as e:
+                yahr_amd.MultiContext(scene, 2, devices=[0, 0], gather=yahr_amd.GATHER_PEER)
+            assert e.value.code == -5, nth
+            assert abs(free_now() - free1) <= slack, ("multi", nth)
+        L.yahr_debug_fail_alloc(0)
+        m = yahr_amd.MultiContext(scene, 2, devices=[0, 0], gather=yahr_amd.GATHER_PEER)
+        free2 = free_now()
+        L.yahr_debug_fail_alloc(2)                                      # growing the buffers for a larger batch fails ...
+        with pytest.raises(yahr_amd.YahrError) as e:
+            m.render(frames=4)
+        assert e.value.code == -5
+        L.yahr_debug_fail_alloc(0)
+        img, _ = m.render(frames=2)                                     # ... and the object is still usable
+        assert img.shape[0] == 2
+        m.close()
+        assert abs(free_now() - free1) <= slack and free2 < free1
         prim, _ = ctx.trace(rays[:4096])                                # and the context is still usable
         assert prim.shape == (4096,)
         ctx.close()
@@ -838,12 +866,104 @@ def test_multi_object_both_transports_on_one_device(gpu):
             if want != yahr_amd.GATHER_NONE:
                 assert m.last_gather_ms > 0
             m.close()
-    one, _ = yahr_amd.render_image(scene, n_devices=1)                     # the one-shot form the CLI uses
+    # the one-shot form the CLI uses: yahr_render_multi itself (render_image(n_devices=1) would take yahr_render_rows)
+    import ctypes as C
+    one = np.zeros_like(full)
+    o = yahr_amd.make_opts()
+    yahr_amd.check(yahr_amd.lib.yahr_render_multi(scene.flat, 1, C.byref(o), one.ctypes.data_as(C.POINTER(C.c_float)), None))
     assert np.array_equal(bits(one), bits(full))
     with pytest.raises(yahr_amd.YahrError):
         yahr_amd.MultiContext(scene, yahr_amd.device_count() + 1)
     with pytest.raises(yahr_amd.YahrError):
-        yahr_amd.MultiContext(scene, 2, devices=[0, 0])
+        yahr_amd.MultiContext(scene, 2, devices=[0, 0])                        # AUTO / RCCL: a device may be listed once
+    with pytest.raises(yahr_amd.YahrError):
+        yahr_amd.MultiContext(scene, 2, devices=[0, 0], gather=yahr_amd.GATHER_RCCL)
+
+
+def _orbit(desc, n):
+    cam = desc.camera
+    rows = []
+    for i in range(n):
+        a = math.radians(3.0 * i)
+        c, s_ = math.cos(a), math.sin(a)
+        p = (c * cam["pos"][0] + s_ * cam["pos"][2], cam["pos"][1], -s_ * cam["pos"][0] + c * cam["pos"][2])
+        l = (c * cam["look"][0] + s_ * cam["look"][2], cam["look"][1], -s_ * cam["look"][0] + c * cam["look"][2])
+        rows.append([cam["imW"], cam["imH"], cam["focal"], *l, *cam["up"], *p])
+    return np.array(rows, dtype=np.float32)
+
+
+@pytest.mark.parametrize("gather", [yahr_amd.GATHER_PEER, yahr_amd.GATHER_RCCL])
+def test_multi_object_frame_batches_and_overlapped_submissions(gpu, gather):
+    """yahr_multi with frame batches (four cameras per submission) and the asynchronous submit / wait pair: two
+    submissions in flight (the exchange + download of one overlap the render of the next), page-locked and pageable
+    host buffers, both transports; every frame bit for bit the stand-alone render of its camera and every submission
+    reporting exactly its own counters."""
+    d = scenes.pseudo_bunny(203, 117, n_lon=48, n_lat=25)
+    scene = d.to_scene().build()
+    cams = _orbit(d, 4)
+    ctx = yahr_amd.Context(scene, 0)
+    alone, counts = [], []
+    for i in range(4):
+        ctx.set_cameras(np.stack([cams[i]] * 2))
+        alone.append(ctx.render(frames=2, collect_stats=True).cpu().numpy()[0])
+        st = ctx.stats()
+        counts.append({k: st[k] // 2 for k in COUNT_KEYS})
+    ctx.close()
+    total = {k: sum(c[k] for c in counts) for k in COUNT_KEYS}
+    m = yahr_amd.MultiContext(scene, 1, gather=gather, strip_rows=8)
+    m.set_cameras(cams)
+    img, st = m.render(frames=4, collect_stats=True)
+    assert img.shape == (4, 117, 203, 3)
+    for f in range(4):
+        assert np.array_equal(bits(img[f]), bits(alone[f])), f
+    assert all(st[k] == total[k] for k in COUNT_KEYS)
+    # pipelined: two in flight, a third is refused until a wait; submissions of different sizes
+    a = m.submit(frames=4, collect_stats=True)
+    b = m.submit(frames=2, collect_stats=True, pinned=False)
+    with pytest.raises(yahr_amd.YahrError):
+        m.submit(frames=1)
+    ra, sa = m.wait()
+    c = m.submit(frames=3, collect_stats=True)
+    rb, sb = m.wait()
+    rc, sc = m.wait()
+    with pytest.raises(yahr_amd.YahrError):
+        m.wait()
+    assert ra is a and rb is b and rc is c
+    for arr, stt, n in ((a, sa, 4), (b, sb, 2), (c, sc, 3)):
+        for f in range(n):
+            assert np.array_equal(bits(arr[f]), bits(alone[f])), (n, f)
+        assert all(stt[k] == sum(counts[f][k] for f in range(n)) for k in COUNT_KEYS), n
+    img1, _ = m.render()                                   # single frames still use camera 0 of the set
+    assert np.array_equal(bits(img1), bits(alone[0]))
+    m.close()
+
+
+@pytest.mark.parametrize("n,strip", [(2, 8), (3, 5), (4, 8)])
+def test_multi_object_n_device_plan_rehearsed_on_one_gpu(gpu, n, strip):
+    """The N-device plan of yahr_multi -- strips dealt round-robin, every entry on its own streams, one strided peer copy
+    per entry into the root's image, cross-stream events, per-entry counters summed -- rehearsed on ONE GPU by listing
+    device 0 N times (allowed with the peer transport named explicitly).  Image bit for bit the unsharded one, counters
+    exact, frame batches and overlapped submissions included.  (Real N-GPU hardware remains unmeasured here.)"""
+    d = scenes.pseudo_bunny(203, 117, n_lon=48, n_lat=25)
+    scene = d.to_scene().build()
+    full, st0 = yahr_amd.render_image(scene, collect_stats=True)
+    m = yahr_amd.MultiContext(scene, n, devices=[0] * n, gather=yahr_amd.GATHER_PEER, strip_rows=strip)
+    assert m.transport == yahr_amd.GATHER_PEER
+    for _ in range(2):
+        img, st = m.render(collect_stats=True)
+        assert np.array_equal(bits(img), bits(full))
+        assert all(st[k] == st0[k] for k in COUNT_KEYS)
+    cams = _orbit(d, 3)
+    m.set_cameras(cams)
+    x = m.submit(frames=3)
+    y = m.submit(frames=3, spp=4, seed=5)
+    m.wait(); m.wait()
+    ctx = yahr_amd.Context(scene, 0)
+    ctx.set_cameras(cams)
+    assert np.array_equal(bits(x), bits(ctx.render(frames=3).cpu().numpy()))
+    assert np.array_equal(bits(y), bits(ctx.render(frames=3, spp=4, seed=5).cpu().numpy()))
+    ctx.close()
+    m.close()
 
 
 def test_stream_form_in_row_bands(gpu, monkeypatch):

@@ -309,6 +309,7 @@ class MultiContext:
         self.scene = scene
         h = C.c_void_p()
         devs = None if devices is None else (C.c_int * len(devices))(*devices)
+        self._pinned, self._inflight = [], []
         check(lib.yahr_multi_create(scene.flat, n_devices, devs, gather, strip_rows, C.byref(h)))
         self._h = h
 
@@ -320,18 +321,51 @@ class MultiContext:
     def last_gather_ms(self):
         return float(lib.yahr_multi_last_gather_ms(self._h))
 
+    def _out(self, frames, pinned):
+        shape = (self.scene.height, self.scene.width, 3) if frames <= 1 else (frames, self.scene.height, self.scene.width, 3)
+        if not pinned:
+            return np.zeros(shape, dtype=np.float32)
+        n = int(np.prod(shape))
+        p = lib.yahr_pinned_alloc(4 * n)
+        if not p:
+            raise MemoryError("yahr_pinned_alloc")
+        self._pinned.append(p)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(n,)).reshape(shape)
+
     def render(self, **kw):
-        """one frame -> (numpy [h, w, 3], stats dict)"""
+        """one frame (or a batch: frames=F) -> (numpy [h, w, 3] or [F, h, w, 3], stats dict)"""
         o = make_opts(**kw)
-        out = np.zeros((self.scene.height, self.scene.width, 3), dtype=np.float32)
+        out = self._out(o.frames, False)
         st = Stats()
         check(lib.yahr_multi_render(self._h, C.byref(o), _fptr(out), C.byref(st)))
         return out, st.as_dict()
+
+    def set_cameras(self, cameras):
+        cams = np.zeros((0, 12), dtype=np.float32) if cameras is None else \
+            np.ascontiguousarray(cameras, dtype=np.float32).reshape(-1, 12)
+        check(lib.yahr_multi_set_cameras(self._h, cams.shape[0], _fptr(cams) if cams.shape[0] else None))
+
+    def submit(self, pinned=True, **kw):
+        """asynchronous: queue a frame batch; returns the (page-locked) host array the matching wait() fills"""
+        o = make_opts(**kw)
+        out = self._out(o.frames, pinned)
+        check(lib.yahr_multi_submit(self._h, C.byref(o), _fptr(out)))
+        self._inflight.append(out)
+        return out
+
+    def wait(self):
+        """complete the oldest submission -> (its host array, its stats)"""
+        st = Stats()
+        check(lib.yahr_multi_wait(self._h, C.byref(st)))
+        return self._inflight.pop(0), st.as_dict()
 
     def close(self):
         h, self._h = getattr(self, "_h", None), None
         if h and lib is not None:
             lib.yahr_multi_destroy(h)
+            for p in getattr(self, "_pinned", []):
+                lib.yahr_pinned_free(p)
+            self._pinned = []
 
     def __del__(self):
         self.close()

@@ -119,6 +119,11 @@ SIGNATURES = {
     "yahr_render_multi": (C.c_int, [C.POINTER(FlatScene), C.c_int, C.POINTER(RenderOpts), _F3, C.POINTER(Stats)]),
     "yahr_multi_create": (C.c_int, [C.POINTER(FlatScene), C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int32, C.POINTER(_VP)]),
     "yahr_multi_render": (C.c_int, [_VP, C.POINTER(RenderOpts), _F3, C.POINTER(Stats)]),
+    "yahr_multi_set_cameras": (C.c_int, [_VP, C.c_int32, _F3]),
+    "yahr_multi_submit": (C.c_int, [_VP, C.POINTER(RenderOpts), _F3]),
+    "yahr_multi_wait": (C.c_int, [_VP, C.POINTER(Stats)]),
+    "yahr_pinned_alloc": (_VP, [C.c_size_t]),
+    "yahr_pinned_free": (None, [_VP]),
     "yahr_multi_transport": (C.c_int, [_VP]),
     "yahr_multi_last_gather_ms": (C.c_double, [_VP]),
     "yahr_multi_destroy": (None, [_VP]),

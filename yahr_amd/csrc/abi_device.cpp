@@ -17,6 +17,8 @@
 
 using yahr::set_error;
 
+void yahr_internal_counters_to_stats(const unsigned long long *h, yahr_stats *out);
+
 struct yahr_ctx {
   int device = 0;
   DScene ds{};
@@ -630,13 +632,7 @@ int yahr_ctx_stats(yahr_ctx *c, yahr_stats *out) {
   unsigned long long h[CTR_TOTAL];
   HIP_TRY(hipMemcpy(h, c->d_ctr, sizeof h, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemset(c->d_ctr, 0, sizeof h));
-  std::memset(out, 0, sizeof *out);
-  out->primary_rays = h[CTR_PRIMARY]; out->reflection_rays = h[CTR_REFLECTION]; out->shadow_rays = h[CTR_SHADOW];
-  out->shaded_hits = h[CTR_SHADED]; out->bad_material = h[CTR_BAD_MAT];
-  out->box_tests = h[CTR_BOX]; out->tri_tests = h[CTR_TRI]; out->sphere_tests = h[CTR_SPH];
-  out->wave_node_steps = h[CTR_WAVE_NODES]; out->wave_prim_steps = h[CTR_WAVE_PRIMS];
-  out->wave_stage1_steps = h[CTR_WAVE_STAGE1]; out->wave_stage2_steps = h[CTR_WAVE_STAGE2];
-  out->max_wave_cycles = h[CTR_MAX_WAVE_CYCLES]; out->sum_wave_cycles = h[CTR_SUM_WAVE_CYCLES];
+  yahr_internal_counters_to_stats(h, out);
   if (c->timed) { float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1)); out->kernel_ms = ms; }
   out->upload_ms = c->upload_ms;
   if (out->bad_material) {
@@ -645,6 +641,30 @@ int yahr_ctx_stats(yahr_ctx *c, yahr_stats *out) {
   }
   return YAHR_OK;
 }
+
+// ---- internal entry points for abi_multi.cpp (not part of the C ABI) ---------------------------------------------
+}  // extern "C"
+hipError_t yahr_internal_dev_alloc(void **p, size_t bytes) { return dev_alloc(p, bytes); }
+int yahr_internal_counter_words(void) { return CTR_TOTAL; }
+// counters of the launches since the last collection -> pinned host memory, then reset; both ordered on `hip_stream`
+// (no host synchronisation: the caller waits for an event it records behind this)
+int yahr_internal_ctx_counters_async(yahr_ctx *c, unsigned long long *host_pinned, void *hip_stream) {
+  hipStream_t st = (hipStream_t)hip_stream;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemcpyAsync(host_pinned, c->d_ctr, sizeof(unsigned long long) * CTR_TOTAL, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemsetAsync(c->d_ctr, 0, sizeof(unsigned long long) * CTR_TOTAL, st));
+  return YAHR_OK;
+}
+void yahr_internal_counters_to_stats(const unsigned long long *h, yahr_stats *out) {
+  std::memset(out, 0, sizeof *out);
+  out->primary_rays = h[CTR_PRIMARY]; out->reflection_rays = h[CTR_REFLECTION]; out->shadow_rays = h[CTR_SHADOW];
+  out->shaded_hits = h[CTR_SHADED]; out->bad_material = h[CTR_BAD_MAT];
+  out->box_tests = h[CTR_BOX]; out->tri_tests = h[CTR_TRI]; out->sphere_tests = h[CTR_SPH];
+  out->wave_node_steps = h[CTR_WAVE_NODES]; out->wave_prim_steps = h[CTR_WAVE_PRIMS];
+  out->wave_stage1_steps = h[CTR_WAVE_STAGE1]; out->wave_stage2_steps = h[CTR_WAVE_STAGE2];
+  out->max_wave_cycles = h[CTR_MAX_WAVE_CYCLES]; out->sum_wave_cycles = h[CTR_SUM_WAVE_CYCLES];
+}
+extern "C" {
 
 static int ray_query(yahr_ctx *c, int32_t n, const float *rays, int which, int traverse, int32_t *iout, float *fout) {
   if (!c || n < 0 || (n && !rays)) { set_error("bad ray query arguments"); return YAHR_E_ARG; }

@@ -154,6 +154,14 @@ int yahr_scene_add_mesh(yahr_host_scene *s, int32_t n_points, const float *point
 int yahr_scene_begin_subsampled(yahr_host_scene *s, float subsample_size);
 int yahr_scene_end_subsampled(yahr_host_scene *s);
 
+/* Who builds the BVH.  The device builder (midpoint split, finite boxes) works level by level on the GPU and yields the
+ * IDENTICAL node array and leaf order as the host builder; AUTO uses it for scenes of 32768 primitives and more when a
+ * device is visible and falls back to the host silently; DEVICE fails the build if it cannot be used. */
+enum { YAHR_BUILDER_AUTO = 0, YAHR_BUILDER_HOST = 1, YAHR_BUILDER_DEVICE = 2 };
+int yahr_scene_set_builder(yahr_host_scene *s, int32_t builder);
+/* after yahr_scene_build: YAHR_BUILDER_HOST or YAHR_BUILDER_DEVICE; *device_ms = device time of the build (0 on the host) */
+int32_t yahr_scene_builder_used(const yahr_host_scene *s, double *device_ms_or_null);
+
 /* `objects >>= expand`, buildCollisionModel, cull: fills the flattened arrays.  Idempotent. */
 int yahr_scene_build(yahr_host_scene *s);
 /* view of the flattened scene (valid until the host scene is modified or freed); builds if needed */
@@ -246,6 +254,9 @@ typedef struct yahr_stats {
 
 void yahr_default_opts(yahr_render_opts *o);
 int yahr_device_count(void);
+/* Bring the HIP runtime, the device and this library's kernel image up (~90 ms the first time in a process): a host may
+ * call it from a second thread while it still parses its scene.  Idempotent; every other entry point works without it. */
+int yahr_device_warmup(int device);
 /* free / total bytes of a device's HBM (hipMemGetInfo after a device synchronise) */
 int yahr_device_mem_info(int device, uint64_t *free_bytes, uint64_t *total_bytes);
 /* Test hook: make the nth device allocation from now on (1 = the next one) fail with out-of-memory, once;

@@ -17,7 +17,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import (GATHER_AUTO, GATHER_NONE, GATHER_PEER, GATHER_RCCL, SPLIT_MIDPOINT, SPLIT_SAH, TILES_REFERENCE, TILES_WAVE, TRAVERSE_AUTO, TRAVERSE_HYBRID, TRAVERSE_STREAM, TRAVERSE_STACK, TRAVERSE_HYBRID_STACK, TRAVERSE_ORDERED,
+from ._lib import (BUILDER_AUTO, BUILDER_DEVICE, BUILDER_HOST, GATHER_AUTO, GATHER_NONE, GATHER_PEER, GATHER_RCCL, SPLIT_MIDPOINT, SPLIT_SAH, TILES_REFERENCE, TILES_WAVE, TRAVERSE_AUTO, TRAVERSE_HYBRID, TRAVERSE_STREAM, TRAVERSE_STACK, TRAVERSE_HYBRID_STACK, TRAVERSE_ORDERED,
                    TRAVERSE_LANE, TRAVERSE_PACKET, TUNE_CENTRE_FIRST, TUNE_ONE_PIXEL_PER_LANE, TUNE_REGROUP, TUNE_XCD_BANDS, RenderOpts, Stats,
                    YahrError, check, lib)
 
@@ -115,6 +115,16 @@ class Scene:
 
     def set_culling(self, max_depth, split=SPLIT_MIDPOINT):
         check(lib.yahr_scene_set_culling(self._h, max_depth, split))
+
+    def set_builder(self, builder):
+        """who builds the BVH: _lib.BUILDER_AUTO / BUILDER_HOST / BUILDER_DEVICE (identical trees)"""
+        check(lib.yahr_scene_set_builder(self._h, builder))
+        return self
+
+    def builder_used(self):
+        """(BUILDER_HOST or BUILDER_DEVICE, device milliseconds) of the last build"""
+        ms = C.c_double()
+        return int(lib.yahr_scene_builder_used(self._h, C.byref(ms))), float(ms.value)
 
     def add_material(self, id, ambient, diffuse, specular, shininess):
         check(lib.yahr_scene_add_material(self._h, id.encode(), _f3(ambient), _f3(diffuse), _f3(specular), shininess))

@@ -13,6 +13,7 @@ ERR_NAMES = {-1: "YAHR_E_ARG", -2: "YAHR_E_PARSE", -3: "YAHR_E_IO", -4: "YAHR_E_
 SPLIT_MIDPOINT, SPLIT_SAH = 0, 1
 TRAVERSE_AUTO, TRAVERSE_LANE, TRAVERSE_PACKET, TRAVERSE_HYBRID, TRAVERSE_STREAM = 0, 1, 2, 3, 4
 TRAVERSE_STACK, TRAVERSE_HYBRID_STACK, TRAVERSE_ORDERED = 5, 6, 7
+BUILDER_AUTO, BUILDER_HOST, BUILDER_DEVICE = 0, 1, 2
 TILES_WAVE, TILES_REFERENCE = 0, 1
 GATHER_AUTO, GATHER_RCCL, GATHER_PEER, GATHER_NONE = 0, 1, 2, 3
 TUNE_XCD_BANDS, TUNE_CENTRE_FIRST, TUNE_REGROUP, TUNE_ONE_PIXEL_PER_LANE = 1, 2, 4, 8      # yahr_render_opts.tuning bits (diagnostics)
@@ -85,6 +86,8 @@ SIGNATURES = {
     "yahr_scene_set_camera": (C.c_int, [_VP, C.c_float, C.c_float, C.c_float, _F3, _F3, _F3]),
     "yahr_scene_set_integrator": (C.c_int, [_VP, C.c_int32]),
     "yahr_scene_set_culling": (C.c_int, [_VP, C.c_int32, C.c_int32]),
+    "yahr_scene_set_builder": (C.c_int, [_VP, C.c_int32]),
+    "yahr_scene_builder_used": (C.c_int32, [_VP, C.POINTER(C.c_double)]),
     "yahr_scene_add_material": (C.c_int, [_VP, C.c_char_p, _F3, _F3, _F3, C.c_float]),
     "yahr_scene_add_light": (C.c_int, [_VP, _F3, _F3]),
     "yahr_scene_add_sphere": (C.c_int, [_VP, _F3, C.c_float, C.c_char_p]),
@@ -101,6 +104,7 @@ SIGNATURES = {
     "yahr_n_batches": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
     "yahr_default_opts": (None, [C.POINTER(RenderOpts)]),
     "yahr_device_count": (C.c_int, []),
+    "yahr_device_warmup": (C.c_int, [C.c_int]),
     "yahr_device_mem_info": (C.c_int, [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "yahr_debug_fail_alloc": (None, [C.c_int32]),
     "yahr_debug_parallel_lists": (C.c_int32, []),

@@ -27,6 +27,7 @@ struct yahr_ctx {
   void *d_nodes = nullptr, *d_prims = nullptr, *d_normals = nullptr, *d_mats = nullptr, *d_lights = nullptr;
   void *d_cold = nullptr;
   void *d_pairs = nullptr;                // child-pair records of the stack walkers (render_kernel.hpp: DPairs), or NULL
+  bool pairs_tried = false;               // ... built on the first use of a stack walker (ensure_pairs)
   DCold cold_host{};
   DCold *d_cams = nullptr; int n_cams = 0;
   int *d_row_order = nullptr; int row_order_n = 0;
@@ -213,6 +214,24 @@ int auto_mode_for(const yahr_scene *s) {
   return biggest > 16 ? TRAV_PACKET : TRAV_STREAM;
 }
 
+// The pair records are built the first time a stack walker is asked for (they cost a pass over the tree and 64 B per
+// interior node, and the default walkers do not use them): from the node array as it sits in device memory.
+int ensure_pairs(yahr_ctx *c) {
+  if (c->pairs_tried) return YAHR_OK;
+  c->pairs_tried = true;
+  if (std::getenv("YAHR_NO_PAIRS") || c->ds.n_nodes < 3) return YAHR_OK;
+  std::vector<yahr_node> nodes((size_t)c->ds.n_nodes), halves;
+  HIP_TRY(hipMemcpy(nodes.data(), c->d_nodes, sizeof(yahr_node) * nodes.size(), hipMemcpyDeviceToHost));
+  yahr_scene view{};
+  view.n_nodes = c->ds.n_nodes; view.nodes = nodes.data();
+  int levels = 0;
+  if (!build_pairs(&view, halves, levels)) return YAHR_OK;          // this scene has none: the walkers use the node array
+  int rc = upload(&c->d_pairs, halves.data(), sizeof(yahr_node) * halves.size());
+  if (rc) { c->pairs_tried = false; return rc; }                     // (out of memory now: try again next time)
+  c->dp.pairs = (const float4 *)c->d_pairs; c->dp.stack_levels = levels;
+  return YAHR_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -227,6 +246,17 @@ int yahr_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
+}
+
+int yahr_device_warmup(int device) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { (void)hipGetLastError(); set_error("no HIP device available (libyahr_hip has no CPU fallback)"); return YAHR_E_NODEVICE; }
+  if (device < 0 || device >= ndev) { set_error("device index out of range"); return YAHR_E_NODEVICE; }
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipFree(nullptr));                              // creates the context
+  HIP_TRY(yahr_dev::launch_warmup(nullptr));              // loads the kernel image
+  HIP_TRY(hipDeviceSynchronize());
+  return YAHR_OK;
 }
 
 int yahr_device_mem_info(int device, uint64_t *free_bytes, uint64_t *total_bytes) {
@@ -305,13 +335,6 @@ int yahr_ctx_create(const yahr_scene *s, int device, yahr_ctx **out) {
   d.cold = (const DCold *)c->d_cold;
   d.n_nodes = s->n_nodes; d.n_prims = s->n_prims; d.n_mats = s->n_mats; d.n_lights = s->n_lights;
   d.depth = s->depth;
-  {
-    std::vector<yahr_node> halves; int levels = 0;
-    if (!std::getenv("YAHR_NO_PAIRS") && build_pairs(s, halves, levels)) {
-      if ((rc = upload(&c->d_pairs, halves.data(), sizeof(yahr_node) * halves.size()))) return rc;
-      c->dp.pairs = (const float4 *)c->d_pairs; c->dp.stack_levels = levels;
-    }
-  }
   c->auto_mode = auto_mode_for(s);
   d.boxes_finite = 1;
   for (int32_t i = 0; i < s->n_nodes && d.boxes_finite; ++i)
@@ -533,6 +556,9 @@ int yahr_ctx_render(yahr_ctx *c, int32_t row0, int32_t row1, const yahr_render_o
   else if (o.stream_walker == YAHR_TRAVERSE_STACK) secondary = TRAV_STACK;
   else if (o.stream_walker == YAHR_TRAVERSE_HYBRID_STACK) secondary = TRAV_ADAPT_STACK;
   else if (o.stream_walker == YAHR_TRAVERSE_ORDERED) secondary = TRAV_ORDERED;
+  if (mode == TRAV_STREAM && (secondary == TRAV_STACK || secondary == TRAV_ADAPT_STACK || secondary == TRAV_ORDERED)) {
+    int rc = ensure_pairs(c); if (rc) return rc;           // (first use: allocates -- warm up before a graph capture)
+  }
   HIP_TRY(hipEventRecord(c->ev0, st));
   if (mode == TRAV_STREAM) {
     const int frames = rp.frames;
@@ -688,7 +714,7 @@ static int ray_query(yahr_ctx *c, int32_t n, const float *rays, int which, int t
     HIP_TRY(hipMemcpy(fout, d_f.p, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost));
   } else {
     if (mode == TRAV_ADAPTIVE && traverse != YAHR_TRAVERSE_HYBRID) mode = TRAV_PACKET;
-    if (walker) mode = walker;
+    if (walker) { mode = walker; int rc = ensure_pairs(c); if (rc) return rc; }
     HIP_TRY(d_i.alloc(sizeof(int) * (size_t)n));
     HIP_TRY(d_f.alloc(sizeof(float) * (size_t)n));
     HIP_TRY(yahr_dev::launch_trace(c->ds, c->dp, mode, n, d_rays.as<float>(), which == 1, d_i.as<int>(), d_f.as<float>(), nullptr));

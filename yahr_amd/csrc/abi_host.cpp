@@ -128,6 +128,15 @@ int yahr_scene_set_culling(yahr_host_scene *s, int32_t max_depth, int32_t split_
   if (!s || (split_mode != YAHR_SPLIT_MIDPOINT && split_mode != YAHR_SPLIT_SAH)) { set_error("bad culling mode"); return YAHR_E_ARG; }
   s->hs->bvh_depth = max_depth; s->hs->split = split_mode; s->hs->invalidate(); return YAHR_OK;
 }
+int yahr_scene_set_builder(yahr_host_scene *s, int32_t builder) {
+  if (!s || builder < YAHR_BUILDER_AUTO || builder > YAHR_BUILDER_DEVICE) { set_error("bad builder"); return YAHR_E_ARG; }
+  s->hs->builder = builder; s->hs->invalidate(); return YAHR_OK;
+}
+int32_t yahr_scene_builder_used(const yahr_host_scene *s, double *device_ms) {
+  if (!s || !s->hs->built) { if (device_ms) *device_ms = 0; return 0; }
+  if (device_ms) *device_ms = s->hs->builder_device_ms;
+  return s->hs->builder_used;
+}
 int yahr_scene_add_material(yahr_host_scene *s, const char *id, const float ambient[3], const float diffuse[3],
                             const float specular[3], float shininess) {
   if (!s || !id || !diffuse || !specular) { set_error("null argument"); return YAHR_E_ARG; }

@@ -419,19 +419,51 @@ void HostScene::build() {
 
   lap("boxes");
   nodes.clear();
-  Builder bld(boxes, nodes, split);
-  lap("centroids");
-  // bvh _ _ [] = const Nothing (Culling.hs:28).  Up to 2^4 subtrees are built concurrently (same tree).
-  int par = std::thread::hardware_concurrency() > 1 ? 4 : 0;
-  if (const char *e = std::getenv("YAHR_BUILD_PAR")) par = std::atoi(e);          // 0 = sequential build (diagnostics)
-  if (!prims.empty()) bld.build(nodes, bvh_depth, 0, (int32_t)prims.size(), par);
+  std::vector<int32_t> leaf_order;                                    // leaf position -> primitive (expand order)
+  // Which builder?  The GPU one (bvh_build.hip) yields the identical node array and leaf order for the midpoint split
+  // of finite boxes; AUTO takes it for big scenes when a device is there (YAHR_BVH_BUILDER=host|device|auto overrides).
+  int want = builder;
+  if (const char *e = std::getenv("YAHR_BVH_BUILDER")) want = !std::strcmp(e, "host") ? YAHR_BUILDER_HOST : !std::strcmp(e, "device") ? YAHR_BUILDER_DEVICE : YAHR_BUILDER_AUTO;
+  builder_used = YAHR_BUILDER_HOST; builder_device_ms = 0; builder_note.clear();
+  if (want != YAHR_BUILDER_HOST) {
+    std::string why;
+    bool ok = split == YAHR_SPLIT_MIDPOINT && prims.size() >= 2 && bvh_depth >= 1 && prims.size() < (size_t)1 << 30;
+    if (!ok) why = "the device builder does the midpoint split of at least two primitives";
+    if (ok && want == YAHR_BUILDER_AUTO && prims.size() < 32768) { ok = false; why = "small scene"; }
+    if (ok) {
+      std::atomic<bool> bad{false};
+      parallel_for(boxes.size(), [&](size_t i) {
+        const Box &b = boxes[i];
+        if (!(std::isfinite(b.lo.x) && std::isfinite(b.lo.y) && std::isfinite(b.lo.z) && std::isfinite(b.hi.x) &&
+              std::isfinite(b.hi.y) && std::isfinite(b.hi.z))) bad.store(true, std::memory_order_relaxed);
+      });
+      if (bad.load()) { ok = false; why = "a primitive's box is not finite"; }
+    }
+    if (ok) ok = device_build_bvh(&boxes[0].lo.x, (int32_t)boxes.size(), bvh_depth, nodes, leaf_order, &builder_device_ms, &why);
+    if (ok) builder_used = YAHR_BUILDER_DEVICE;
+    else {
+      builder_note = why;
+      if (want == YAHR_BUILDER_DEVICE) throw std::runtime_error("device BVH build not possible: " + why);
+    }
+  }
+  if (builder_used == YAHR_BUILDER_HOST) {
+    nodes.clear();
+    Builder bld(boxes, nodes, split);
+    lap("centroids");
+    // bvh _ _ [] = const Nothing (Culling.hs:28).  Up to 2^4 subtrees are built concurrently (same tree).
+    int par = std::thread::hardware_concurrency() > 1 ? 4 : 0;
+    if (const char *e = std::getenv("YAHR_BUILD_PAR")) par = std::atoi(e);          // 0 = sequential build (diagnostics)
+    if (!prims.empty()) bld.build(nodes, bvh_depth, 0, (int32_t)prims.size(), par);
+    leaf_order.resize(prims.size());
+    parallel_for(prims.size(), [&](size_t i) { leaf_order[i] = bld.order[i].id; });
+  }
 
   lap("tree");
   prim_recs.resize(prims.size()); prim_normals.resize(prims.size());
   parallel_for(prims.size(), [&](size_t i) {
-    const Primitive &p = prims[bld.order[i].id];
+    const Primitive &p = prims[leaf_order[i]];
     yahr_prim r{}; yahr_prim_normals nr{};
-    r.mat = p.mat; r.kind = p.kind; r.orig = bld.order[i].id;
+    r.mat = p.mat; r.kind = p.kind; r.orig = leaf_order[i];
     put3(r.p0, p.p0);
     if (p.kind == 1) { r.e1[0] = p.radius; }
     else {

@@ -57,8 +57,11 @@ struct HostScene {
   std::vector<SceneObject> objects;
   std::vector<SceneObject *> open_subsampled;   // programmatic begin/end nesting
 
+  int builder = 0;                         // YAHR_BUILDER_*: who builds the BVH (yahr_scene_set_builder)
+
   // built state
   bool built = false;
+  int builder_used = 0; double builder_device_ms = 0; std::string builder_note;   // what did, device time, why not the GPU
   std::vector<Primitive> prims;            // expand order
   std::vector<yahr_node> nodes;
   std::vector<yahr_prim> prim_recs;
@@ -83,6 +86,11 @@ void expand_object(const SceneObject &o, const std::function<int32_t(const std::
                    std::vector<Primitive> &out);
 // Cameras.hs:58-81: fills tf and vtf (row-major)
 void camera_matrices(const Camera &c, float tf[16], float vtf[16]);
+
+// bvh_build.hip: the midpoint BVH built on the GPU with the identical result (node array and leaf order); false = not
+// possible here (no device, out of memory, ...), nothing written
+bool device_build_bvh(const float *boxes, int32_t n, int max_depth, std::vector<yahr_node> &nodes, std::vector<int32_t> &order,
+                      double *device_ms, std::string *why);
 
 void set_error(const std::string &msg);
 

@@ -1319,6 +1319,12 @@ hipError_t launch_radiance(const DScene &sc, int mode, int n, const float *rays,
   return hipGetLastError();
 }
 
+__global__ void k_warmup() {}
+hipError_t launch_warmup(hipStream_t st) {
+  hipLaunchKernelGGL(k_warmup, dim3(1), dim3(64), 0, st);
+  return hipGetLastError();
+}
+
 hipError_t launch_camera_rays(const DScene &sc, int n, const float *uv, float *rays, hipStream_t st) {
   hipLaunchKernelGGL(k_camera_rays, dim3((n + 255) / 256), dim3(256), 0, st, sc, n, uv, rays);
   return hipGetLastError();

@@ -31,10 +31,9 @@ struct yahr_ctx {
   DCold cold_host{};
   DCold *d_cams = nullptr; int n_cams = 0;
   int *d_row_order = nullptr; int row_order_n = 0;
-  int auto_mode = TRAV_PACKET;
-  int stream_secondary = TRAV_ADAPTIVE;   // walker of the secondary rays in the stream form (measured on 1 M triangles, 16 spp,
-                                          // paths in Morton order: adaptive 38.3 ms, packet 39.7, lane 41.7; in image order
-                                          // adaptive 47.9 = lane 47.9, packet 77.8)
+  int auto_mode = TRAV_PACKET;            // AUTO: the fused kernel's walker ...
+  size_t auto_stream_min = (size_t)-1;    // ... and from how many samples per launch on the wavefront form instead
+  int stream_secondary = TRAV_ADAPTIVE;   // walker of the secondary rays in the wavefront form (auto_policy_for)
   unsigned long long *d_ctr = nullptr;
   int4 *d_windows = nullptr; int n_windows = 0, n_chunks = 0, windows_w = 0, windows_h = 0;
   // wavefront ("stream") form: path queues, per-level results, queue lengths (allocated on first use, grown on demand)
@@ -197,21 +196,32 @@ bool build_pairs(const yahr_scene *s, std::vector<yahr_node> &halves, int &level
   return levels <= 48 && (uint64_t)n_int * 64 <= 0xffffffffULL;
 }
 
-// AUTO policy.  Measured per frame at 1080p (ms: lane / packet / adaptive): pseudo-bunny (largest leaf 70)
-// 1.66 / 0.68 / 1.34; 200k random triangles (BVH 16: 0.13 M nodes, largest leaf 12) 4.10 / 2.92 / 3.39 (16 spp:
-// - / 13.0 / 17.0); 1M random triangles (BVH 20: 1.6 M nodes, largest leaf 7) 7.72 / 20.2 / 7.24 (16 spp: 75 / 73 / 62,
-// wavefront form 47.9); 8 spheres + 2 triangles 0.146 / 0.137 / 0.160.  The packet walker wins wherever the union of
-// 64 paths stays small: fat multi-leaves (scalar primitive broadcast), tiny scenes, moderately deep trees.  Only a
-// very deep tree of thin leaves under incoherent secondary rays makes the union explode: more than half a million
-// nodes and no leaf above 16 primitives -> the wavefront ("stream") form, whose secondary rays run compacted in the
-// adaptive walker (yahr_ctx_render falls back to the fused adaptive kernel when the path queues do not fit the
-// device or the launch uses reference tiles); everything else -> packet.
-int auto_mode_for(const yahr_scene *s) {
-  if (s->n_prims <= 64 || s->n_nodes <= 500000) return TRAV_PACKET;
+// AUTO policy, from a sweep, not from the benchmark scenes: random triangles 50 k .. 4 M x BVH depth 16 / 20 x 1 / 4 / 16 /
+// 64 spp at 1080p in every form (tools/auto_sweep.py, table in profiles/r03_auto_sweep.csv; ms per frame).  What it says:
+//   * below ~100 k primitives the packet walker wins at every sample count (50 k: 0.73 / 1.47 / 4.13 / 14.2 ms against
+//     1.80 / 1.85 / 4.09 / 17.2 in the wavefront form): tiny trees, the union of 64 paths stays small;
+//   * from 200 k primitives on the wavefront ("stream") form wins as soon as a launch holds enough paths to fill its level
+//     launches -- 4 spp at 1080p (8 M samples) everywhere (200 k: 4.6 against 5.2; 1 M: 14.3 against 20.6 .. 46.7; 4 M:
+//     46 .. 142 against 68 .. 223) -- whatever the tree depth and the leaf size;
+//   * at 1 spp (2 M samples) it still wins where leaves are FAT (more than 16 primitives: 1 M in a depth-16 tree 17.0
+//     against 23.9, 4 M 63.7 against 99.8), not where they are thin (1 M in a depth-20 tree: fused adaptive 7.0, stream
+//     9.5, packet 16.1; 200 k, depth 20: adaptive 2.1, packet 2.9, stream 3.9): there the fused kernel runs, the adaptive
+//     walker for a big tree (more than 300 k nodes), the packet walker otherwise (200 k, depth 16: 2.8 against 3.4);
+//   * secondary rays of the wavefront form: on fat leaves the stack walker after the packet start is 5-10 % ahead of the
+//     skip-link lane walker (1 M, depth 16: 17.0 / 29.4 / 64.5 / 162 against 18.3 / 31.6 / 67.0 / 165), on thin leaves
+//     2-5 % behind (1 M, depth 20, 16 spp: 35.7 against 34.0).
+struct AutoPolicy { int fused; size_t stream_min_samples; int secondary; };
+AutoPolicy auto_policy_for(const yahr_scene *s) {
+  AutoPolicy p{TRAV_PACKET, (size_t)-1, TRAV_ADAPTIVE};                  // (size_t)-1: never the wavefront form
+  if (s->n_prims < 100000) return p;
   int32_t biggest = 0;
   for (int32_t i = 0; i < s->n_nodes; ++i)
     if (s->nodes[i].b >= 0 && s->nodes[i].a > biggest) biggest = s->nodes[i].a;
-  return biggest > 16 ? TRAV_PACKET : TRAV_STREAM;
+  const bool fat = biggest > 16;
+  p.fused = (!fat && s->n_nodes > 300000) ? TRAV_ADAPTIVE : TRAV_PACKET;
+  p.stream_min_samples = fat ? ((size_t)2 << 20) - 65536 : (size_t)3 << 20;   // fat: one 1080p frame at 1 spp is enough
+  p.secondary = fat ? TRAV_ADAPT_STACK : TRAV_ADAPTIVE;
+  return p;
 }
 
 // The pair records are built the first time a stack walker is asked for (they cost a pass over the tree and 64 B per
@@ -335,7 +345,7 @@ int yahr_ctx_create(const yahr_scene *s, int device, yahr_ctx **out) {
   d.cold = (const DCold *)c->d_cold;
   d.n_nodes = s->n_nodes; d.n_prims = s->n_prims; d.n_mats = s->n_mats; d.n_lights = s->n_lights;
   d.depth = s->depth;
-  c->auto_mode = auto_mode_for(s);
+  { const AutoPolicy ap = auto_policy_for(s); c->auto_mode = ap.fused; c->auto_stream_min = ap.stream_min_samples; c->stream_secondary = ap.secondary; }
   d.boxes_finite = 1;
   for (int32_t i = 0; i < s->n_nodes && d.boxes_finite; ++i)
     for (int k = 0; k < 3; ++k)
@@ -524,12 +534,10 @@ int yahr_ctx_render(yahr_ctx *c, int32_t row0, int32_t row1, const yahr_render_o
     n_blocks *= rp.frames;
   }
   int mode = pick_mode(o.traverse, c->auto_mode);
-  // AUTO: the wavefront form needs enough paths per launch to fill the chip -- its level launches hold a third of the
-  // samples or fewer (1 M triangles, 1080p: 1 spp fused adaptive 7.0 ms against 9.3, 2 spp 11.5 against 10.4, 16 spp
-  // 60.2 against 34.4)
-  if (o.traverse == YAHR_TRAVERSE_AUTO && mode == TRAV_STREAM &&
-      (size_t)rp.n_local_rows * (size_t)c->width * (size_t)(o.spp > 0 ? o.spp : 1) < ((size_t)3 << 20))
-    mode = TRAV_ADAPTIVE;
+  // AUTO: the wavefront form once a launch holds enough paths to fill its level launches (auto_policy_for)
+  if (o.traverse == YAHR_TRAVERSE_AUTO &&
+      (size_t)rp.n_local_rows * (size_t)c->width * (size_t)(o.spp > 0 ? o.spp : 1) >= c->auto_stream_min)   // (per frame: a batch is rendered frame by frame in that form)
+    mode = TRAV_STREAM;
   int band_rows = 0, tile_h = 1;
   if (mode == TRAV_STREAM) {
     // per frame of the batch and per band of rows: camera-ray launch, one launch per recursion level, resolve
@@ -542,7 +550,7 @@ int yahr_ctx_render(yahr_ctx *c, int32_t row0, int32_t row1, const yahr_render_o
         set_error("stream traversal needs wave tiles, no tuning bits, and device memory for the queues of one tile row");
         return YAHR_E_ARG;
       }
-      mode = TRAV_ADAPTIVE;                                                // AUTO: the fused kernel
+      mode = c->auto_mode;                                                 // AUTO: the fused kernel
     }
   }
   // walker of the stream form's secondary rays: the context's choice, or the one the caller names

@@ -449,6 +449,10 @@ YD int packet_step(const DScene &sc, const NodeRec &cur, NodeRec &nxt, int i, V3
     packet_box<FAST>(cur, on, o, inv, tmax, h, anyh);
     if (anyh) {
       bool got = false;
+#ifdef YAHR_PRIO_FAT
+      // a wavefront inside a fat multiLeaf is on a long serial chain: let it issue ahead of its SIMD's other waves
+      if (a >= YAHR_PRIO_FAT) __builtin_amdgcn_s_setprio(3);
+#endif
       // two primitives per trip, the record buffers swapped: the prefetch of the next record (padded array) never
       // has to be copied into place (12 SGPR moves per primitive otherwise)
       for (int k = 0; k < a; k += 2) {
@@ -460,6 +464,9 @@ YD int packet_step(const DScene &sc, const NodeRec &cur, NodeRec &nxt, int i, V3
         if (STATS) c.wave_prims++;
         got |= test_prim_packet<STATS>(sc, b + k + 1, p1, h & !(any_hit & got), o, u, tmax, hit, c);
       }
+#ifdef YAHR_PRIO_FAT
+      if (a >= YAHR_PRIO_FAT) __builtin_amdgcn_s_setprio(0);
+#endif
       if (any_hit) {
         if (got) wake = YD_DONE;
         if (wany(got)) {

@@ -84,15 +84,17 @@ def test_no_fma_contraction(asm):
 
 
 def test_register_budget_and_no_scratch(asm):
-    # packet walker (issue bound): 7 waves per SIMD = 72 VGPRs; the few values that do not fit may be spilled in the
-    # kernel's prologue / epilogue, never inside the loop nest
+    # packet walker (issue bound): 7 waves per SIMD = 72 VGPRs and NO scratch at all in the kernel of the benchmark: the
+    # pixel's identity is recomputed for the final store instead of being carried (and spilled) through the radiance
+    # computation -- until round 3 six spilled dwords per lane made 290 MB of scratch writes per 8-frame launch
     for k in (PACKET_FAST, PACKET_REGROUP):
         m = meta(asm, k)
         assert m["vgpr_count"] <= 72, m
         assert m["vgpr_spill_count"] <= 32, m
         if k != PACKET_FAST:                                     # the regrouping variant is a diagnostics build
             continue
-        assert m["vgpr_spill_count"] <= 8, m
+        assert m["vgpr_spill_count"] == 0 and m["private_segment_fixed_size"] == 0, m
+        assert "scratch_" not in kernel_body(asm, k)
         lines = kernel_body(asm, k).split("\n")
         # the traversal loops: from the first depth-3 loop header (node loop; the primitive loops are depth 4) to
         # the depth-2 inner loop that follows them (the fold of the radiance levels)
@@ -107,7 +109,7 @@ def test_register_budget_and_no_scratch(asm):
     for k in (LANE_FAST, ADAPTIVE_FAST):
         m = meta(asm, k)
         assert m["vgpr_count"] <= 64, m
-        assert m["vgpr_spill_count"] <= 56, m
+        assert m["vgpr_spill_count"] <= 40, m                      # (lane 12, adaptive 36 as of round 3)
 
 
 # the wavefront form: k_stream_primary<STATS>, k_stream_level<MODE, STATS>, the counting sort and the resolve kernels

@@ -805,67 +805,48 @@ YD void flush_counters(const Counters &c, unsigned long long *ctr, int lane) {
 // lane -> pixel for the 8x8 wave tiles (tile_mode 0), with samples in lanes and row sharding:
 // lane -> (pixel of the tile, sample of the round): q-th pixel of a (64 >> sil) pixel block, 2^pw wide;
 // local row -> global image row (row sharding, include/yahr_hip.h yahr_render_opts)
-YD void tile_pixel(const RParams &rp, int tx, int ty, bool tile_ok, int lane, int &u, int &gv, size_t &row, bool &valid) {
+YD void wave_tile_pixel(const RParams &rp, int tile, int lane, int &u, int &gv, size_t &row, bool &valid) {
+  int ty = tile / rp.tiles_x;
+  const int tx = tile - ty * rp.tiles_x;
+  // optional permutation of the tile rows (diagnostics; centre-rows-first measured slower than natural order)
+  if (rp.row_order && tile < rp.n_tiles) ty = rp.row_order[ty];
   const int q = lane >> rp.sil_log2;
   const int pw = 1 << rp.pw_log2, ph = (64 >> rp.sil_log2) >> rp.pw_log2;
   u = tx * pw + (q & (pw - 1));
   const int lv = ty * ph + (q >> rp.pw_log2);
-  // (launch parameters that steer branches or divide are made opaque: as invariants of the sample loop the compiler
-  // hoisted the conditions and the reciprocals out of it and kept them -- spilled -- across the whole radiance
-  // computation; see pixel_of)
-  int n_shards = rp.n_shards;
-  asm("" : "+s"(n_shards));
-  gv = rp.row0 + lv;                                   // one shard: rows [row0, row0 + n_local_rows)
-  if (n_shards > 1) {                                  // wave-uniform: a per-lane division only when rows are dealt out
-    int strip_rows = rp.strip_rows;
-    asm("" : "+s"(strip_rows));
-    const int strip = lv / strip_rows;
-    gv = rp.row0 + strip * strip_rows * n_shards + (lv - strip * strip_rows);
-  }
-  valid = tile_ok && u < rp.width && lv < rp.n_local_rows && gv < rp.height;
+  const int strip = lv / rp.strip_rows;
+  gv = rp.row0 + strip * rp.strip_rows * rp.n_shards + (lv - strip * rp.strip_rows);
+  valid = tile < rp.n_tiles && u < rp.width && lv < rp.n_local_rows && gv < rp.height;
   row = (size_t)lv;
 }
-YD void wave_tile_pixel(const RParams &rp, int tile, int lane, int &u, int &gv, size_t &row, bool &valid) {
-  int tiles_x = rp.tiles_x;
-  asm("" : "+s"(tiles_x));
-  int ty = tile / tiles_x;
-  const int tx = tile - ty * tiles_x;
-  // optional permutation of the tile rows (diagnostics; centre-rows-first measured slower than natural order)
-  if (rp.row_order && tile < rp.n_tiles) ty = rp.row_order[ty];
-  tile_pixel(rp, tx, ty, tile < rp.n_tiles, lane, u, gv, row, valid);
-}
 
-// Which pixel does this lane render?  frame of the batch, pixel (u, gv), output row, and whether there is one.  The ids are
-// laundered through empty asm statements so that two calls are two computations (see k_render).  Returns the lane id.
-template <int WPB, bool DEEP>
-YD int pixel_of(const RParams &rp, int &frame, int &u, int &gv, size_t &row, bool &valid) {
-  unsigned blk = blockIdx.x; int tid = threadIdx.x;
-  asm("" : "+s"(blk)); asm("" : "+v"(tid));
-  // ... and so are the launch parameters the branches below test: as loop invariants of the sample loop the compiler
-  // hoisted those conditions and kept them in VGPRs (0 / 1) across the whole radiance computation -- spilled, again
-  int n_frames = rp.frames, tile_mode = rp.tile_mode, swz = rp.xcd_swizzle, grid3d = rp.grid3d;
-  asm("" : "+s"(n_frames)); asm("" : "+s"(tile_mode)); asm("" : "+s"(swz)); asm("" : "+s"(grid3d));
-  const int lane = tid & 63, wave = tid >> 6;
-  if (WPB == 1 && !DEEP && grid3d) {
-    // the usual launch: a 3-D grid (frame, tile column, tile row) -- dispatched x fastest, so the same tile of every frame
-    // of a batch still sits next to each other -- and no integer division at all on the way to the pixel
-    unsigned by = blockIdx.y, bz = blockIdx.z;
-    asm("" : "+s"(by)); asm("" : "+s"(bz));
-    frame = (int)blk;
-    tile_pixel(rp, (int)by, (int)bz, true, lane, u, gv, row, valid);
-    return lane;
-  }
+// One wavefront per tile: an 8x8-pixel tile, or one of the reference's squareBatches windows (Sampling.hs:5-21)
+// walked 64 pixels at a time, u-major like the reference.  WPB = 1: one wave per workgroup.  WPB = 4: a
+// workgroup owns 2x2 tiles (or 4 consecutive window chunks) and regroups its rays before every traversal
+// (traverse_block).
+template <int MODE, bool STATS, int WPB, bool DEEP = false>
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(MODE == TRAV_PACKET ? YAHR_WAVES : YAHR_WAVES_LANE, 8)))
+void k_render(DScene sc_in, YD_SCENE_PARAMS, RParams rp, float *__restrict__ out, unsigned long long *__restrict__ ctr) {
+  extern __shared__ float lds[];
+  YD_SCENE_BIND
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float *xch = lds + (size_t)(sc.depth > 0 ? sc.depth : 1) * 6 * 64 * WPB;   // exchange area (WPB > 1 only; never DEEP)
+  // DEEP: this workgroup's slice of the level spill (levels beyond the LDS part; only ever touched by such levels)
+  float *spill = DEEP ? rp.lvl_spill + (size_t)blockIdx.x * (size_t)(sc.depth - rp.lds_levels) * (6 * 64 * WPB) : nullptr;
+  Counters c = {};
+  bool bad_mat = false;
+  const unsigned long long t_start = STATS ? clock64() : 0ULL;
   // frame batch: the same tile of every frame of the batch sits next to each other in dispatch order
-  const unsigned bid = DEEP ? blk + rp.block0 : blk;   // (DEEP: a launch may be one chunk of a grid)
-  frame = n_frames > 1 ? (int)(bid % (unsigned)n_frames) : 0;
-  const int unit = n_frames > 1 ? (int)(bid / (unsigned)n_frames) : (int)bid;
+  const unsigned bid = DEEP ? blockIdx.x + rp.block0 : blockIdx.x;   // (DEEP: a launch may be one chunk of a grid)
+  const int frame = rp.frames > 1 ? (int)(bid % (unsigned)rp.frames) : 0;
+  const int unit = rp.frames > 1 ? (int)(bid / (unsigned)rp.frames) : (int)bid;
   int tile = unit;
   if (WPB == 1) {
-    if (tile_mode == 0 && swz) {                       // diagnostics: contiguous band of tiles per XCD
+    if (rp.tile_mode == 0 && rp.xcd_swizzle) {         // diagnostics: contiguous band of tiles per XCD
       const int per = (rp.n_tiles + 7) >> 3;
       tile = (tile & 7) * per + (tile >> 3);
     }
-  } else if (tile_mode == 0) {                         // 2x2 tiles per workgroup
+  } else if (rp.tile_mode == 0) {                      // 2x2 tiles per workgroup
     const int ux_n = (rp.tiles_x + 1) >> 1;
     const int uy = unit / ux_n, ux = unit - uy * ux_n;
     const int tx = ux * 2 + (wave & 1), ty = uy * 2 + (wave >> 1);
@@ -873,7 +854,13 @@ YD int pixel_of(const RParams &rp, int &frame, int &u, int &gv, size_t &row, boo
   } else {
     tile = unit * WPB + wave;
   }
-  if (tile_mode == 0) {
+  const DCold *cam = rp.cams ? rp.cams + frame : sc.cold;
+  out += (size_t)frame * rp.frame_stride;
+  // NOTE: the ONLY global stores of this kernel come after the last traversal.  A store (or atomic) ahead of
+  // a scene load makes that load "clobberable" for the compiler, which then refuses the scalar-load path and
+  // silently turns the packet walker's node fetches into per-lane gathers (tests/test_isa.py guards this).
+  int u, gv; size_t row; bool valid;
+  if (rp.tile_mode == 0) {
     wave_tile_pixel(rp, tile, lane, u, gv, row, valid);
   } else {
     // 64-pixel chunk of a reference window: {x0,y0,x1,y1}, {first pixel of the chunk, ...}; u-major order
@@ -886,69 +873,33 @@ YD int pixel_of(const RParams &rp, int &frame, int &u, int &gv, size_t &row, boo
     gv = valid ? win.y + p % hh : 0;
     row = (size_t)gv;
   }
-  return lane;
-}
-
-// One wavefront per tile: an 8x8-pixel tile, or one of the reference's squareBatches windows (Sampling.hs:5-21)
-// walked 64 pixels at a time, u-major like the reference.  WPB = 1: one wave per workgroup.  WPB = 4: a
-// workgroup owns 2x2 tiles (or 4 consecutive window chunks) and regroups its rays before every traversal
-// (traverse_block).
-template <int MODE, bool STATS, int WPB, bool DEEP = false>
-__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(MODE == TRAV_PACKET ? YAHR_WAVES : YAHR_WAVES_LANE, 8)))
-void k_render(DScene sc_in, YD_SCENE_PARAMS, RParams rp, float *__restrict__ out, unsigned long long *__restrict__ ctr) {
-  extern __shared__ float lds[];
-  YD_SCENE_BIND
-  float *xch = lds + (size_t)(sc.depth > 0 ? sc.depth : 1) * 6 * 64 * WPB;   // exchange area (WPB > 1 only; never DEEP)
-  // DEEP: this workgroup's slice of the level spill (levels beyond the LDS part; only ever touched by such levels)
-  float *spill = DEEP ? rp.lvl_spill + (size_t)blockIdx.x * (size_t)(sc.depth - rp.lds_levels) * (6 * 64 * WPB) : nullptr;
-  Counters c = {};
-  bool bad_mat = false;
-  const unsigned long long t_start = STATS ? clock64() : 0ULL;
-  // NOTE: the ONLY global stores of this kernel come after the last traversal.  A store (or atomic) ahead of
-  // a scene load makes that load "clobberable" for the compiler, which then refuses the scalar-load path and
-  // silently turns the packet walker's node fetches into per-lane gathers (tests/test_isa.py guards this).
   V3 acc = vof(0.0f);
   // One sample loop for both lane layouts (ONE radiance call site: it is the whole kernel, inlined).
   //  * sil_log2 == 0: a lane is a pixel and takes its samples one after the other;
   //  * samples in lanes: the wave's rays go through a few neighbouring pixels (ONE pixel at 64 spp), so the packet
   //    walks hardly more than a single ray's path.  The pixel is still the sum of its samples IN SAMPLE ORDER
   //    (left fold from 0): the samples of a round are parked in LDS and the pixel's first lane adds them up.
-  // Which pixel a lane renders is RECOMPUTED where it is needed -- at the top of every sample round and for the final
-  // store -- from block and thread ids made opaque to common-subexpression elimination: carried through the radiance
-  // computation instead, these values (pixel, row, frame, output pointer) were the registers the packet kernel spilled
-  // to scratch (six dwords per lane: 290 MB of scratch writes per 8-frame launch).
-  const int sw = 1 << rp.sil_log2;
+  const int sw = 1 << rp.sil_log2, j0 = lane & (sw - 1);
   for (int s0 = 0; s0 < rp.spp; s0 += sw) {
-    int frame, u, gv; size_t row; bool valid;
-    const int lane = pixel_of<WPB, DEEP>(rp, frame, u, gv, row, valid);
-    const int j0 = lane & (sw - 1);
-    const DCold *cam = rp.cams ? rp.cams + frame : sc.cold;
     float du = 0.0f, dv = 0.0f;                        // spp == 1: the integer pixel corner (main.hs:73)
-    int spp = rp.spp, n_strata = rp.n_strata;          // (opaque, like the divisors of pixel_of: no hoisted reciprocals)
-    asm("" : "+s"(spp)); asm("" : "+s"(n_strata));
-    if (spp > 1) sample_offset(u, gv, s0 + j0, n_strata, rp.seed, du, dv);
+    if (rp.spp > 1) sample_offset(u, gv, s0 + j0, rp.n_strata, rp.seed, du, dv);
     V3 ro, rd;
     camera_ray(cam, (float)u + du, (float)gv + dv, ro, rd);
     const V3 v = radiance<MODE, STATS, WPB, DEEP>(sc, valid, ro, rd, lds, xch, c, bad_mat, spill, rp.lds_levels);
     if (rp.sil_log2 == 0) {
       acc = (rp.spp > 1) ? acc + v : v;
     } else {
-      const int ln = threadIdx.x & 63;
       float *park = lds;                               // the radiance stack of this wave is free again
-      park[ln] = v.x; park[64 + ln] = v.y; park[128 + ln] = v.z;
+      park[lane] = v.x; park[64 + lane] = v.y; park[128 + lane] = v.z;
       // the pixel's first lane reads what the OTHER lanes of its wavefront stored: order the LDS accesses explicitly
       // (the DS unit serves one wavefront's operations in order; this keeps the compiler from moving them, too)
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
-      if ((ln & (sw - 1)) == 0)
-        for (int k = 0; k < sw; ++k) acc = acc + v3(park[ln + k], park[64 + ln + k], park[128 + ln + k]);
+      if (j0 == 0)
+        for (int k = 0; k < sw; ++k) acc = acc + v3(park[lane + k], park[64 + lane + k], park[128 + lane + k]);
     }
   }
-  int frame, u, gv; size_t row; bool valid;
-  const int lane = pixel_of<WPB, DEEP>(rp, frame, u, gv, row, valid);
-  const int j0 = lane & (sw - 1);
-  out += (size_t)frame * rp.frame_stride;
   if (rp.sil_log2 != 0) valid = valid && j0 == 0;      // the pixel's first lane stores it
   if (rp.spp > 1) acc = scale(1.0f / (float)rp.spp, acc);
   if (valid) {
@@ -1025,13 +976,8 @@ YD void q_append(const DScene &sc, const SParams &sp, int level_out, bool alive,
 
 // camera rays: one wavefront per wave tile (same lane -> pixel/sample layout as k_render), closest hit with the
 // packet walker (camera rays are coherent), DifferentialGeometry of the hits -> queue 0
-// the camera-ray launch of the wavefront form carries no radiance state: 64 VGPRs hold it, and all 8 wave slots of a SIMD
-// pay (1 M triangles, 16 spp: 33.4 ms per frame at 8 waves, 34.0 at 7, 34.8 at 6)
-#ifndef YAHR_WAVES_PRIMARY
-#define YAHR_WAVES_PRIMARY 8
-#endif
 template <bool STATS>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(YAHR_WAVES_PRIMARY, 8)))
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(YAHR_WAVES, 8)))
 void k_stream_primary(DScene sc_in, YD_SCENE_PARAMS, RParams rp, SParams sp, unsigned long long *__restrict__ ctr) {
   YD_SCENE_BIND
   const int lane = threadIdx.x & 63;
@@ -1289,9 +1235,8 @@ static hipError_t launch_render_mode(const DScene &sc, const RParams &rp, int n_
     else hipLaunchKernelGGL((k_render<MODE, false, 1, true>), dim3(n_blocks), dim3(64), lds_bytes, st, sc, sc.nodes, sc.prims, sc.normals, rp, out, ctr);
     return hipGetLastError();
   }
-  const dim3 grid = (WPB == 1 && rp.grid3d) ? dim3((unsigned)rp.frames, (unsigned)rp.tiles_x, (unsigned)rp.tile_rows) : dim3((unsigned)n_blocks);
-  if (stats) hipLaunchKernelGGL((k_render<MODE, true, WPB>), grid, dim3(64 * WPB), lds_bytes, st, sc, sc.nodes, sc.prims, sc.normals, rp, out, ctr);
-  else hipLaunchKernelGGL((k_render<MODE, false, WPB>), grid, dim3(64 * WPB), lds_bytes, st, sc, sc.nodes, sc.prims, sc.normals, rp, out, ctr);
+  if (stats) hipLaunchKernelGGL((k_render<MODE, true, WPB>), dim3(n_blocks), dim3(64 * WPB), lds_bytes, st, sc, sc.nodes, sc.prims, sc.normals, rp, out, ctr);
+  else hipLaunchKernelGGL((k_render<MODE, false, WPB>), dim3(n_blocks), dim3(64 * WPB), lds_bytes, st, sc, sc.nodes, sc.prims, sc.normals, rp, out, ctr);
   return hipGetLastError();
 }
 

@@ -621,6 +621,12 @@ int yahr_ctx_render(yahr_ctx *c, int32_t row0, int32_t row1, const yahr_render_o
       }
       rp.lvl_spill = (float *)c->d_spill;
     }
+    // the usual launch as a 3-D grid (frame, tile column, tile row): no integer division on the way to the pixel
+    rp.grid3d = 0;
+    if (rp.tile_mode == 0 && !regroup && !rp.xcd_swizzle && rp.row_order == nullptr && extra == 0 && rp.tiles_x > 0) {
+      rp.tile_rows = rp.n_tiles / rp.tiles_x;
+      if (rp.tile_rows <= 65535 && rp.tiles_x <= 65535) rp.grid3d = 1;
+    }
     for (int b0 = 0; b0 < n_blocks; b0 += chunk) {
       rp.block0 = (unsigned)b0;
       HIP_TRY(yahr_dev::launch_render(c->ds, rp, mode, regroup, std::min(chunk, n_blocks - b0), d_rgb, c->d_ctr, o.collect_stats != 0, st));

@@ -65,6 +65,9 @@ struct RParams {
   float *lvl_spill;
   int lds_levels;
   unsigned block0;
+  // the usual launch (8x8 wave tiles, one wave per workgroup, natural order, no level spill) is a 3-D grid
+  // (frames, tiles_x, tile_rows): blockIdx is (frame, tile column, tile row) and nothing has to be divided
+  int grid3d, tile_rows;
 };
 // Scenes of recursion depth <= YD_LDS_DEPTH keep the whole radiance stack in LDS (1.5 KiB per level and wavefront);
 // deeper ones keep YD_LDS_LEVELS levels there (4.5 KiB: room for 32 wavefronts per CU) and the rest in the spill.

@@ -62,7 +62,7 @@ def test_packet_walker_uses_scalar_loads(asm):
     assert x8 >= 5 and x4 >= 4, (x8, x4)
     # ... and what is left on the vector path is the per-lane data only (normals of candidate hits, shading)
     # (the window records of the reference tiling are loaded where the pixel is worked out, i.e. twice since round 3)
-    assert vmem <= 20, vmem
+    assert vmem <= 24, vmem
     lane = kernel_body(asm, LANE_FAST)
     assert len(re.findall(r"global_load_dword", lane)) >= 10      # the lane walker gathers per lane, by design
     # the record arrays are `const __restrict__` kernel arguments, so counters (atomics, clock reads) and the

@@ -103,7 +103,7 @@ def test_reference_e2e_scene(gpu):
 
 @pytest.mark.parametrize("depth", [0, 1, 2, 4, 5, 7, 43, 64, 300])
 def test_recursion_depths(gpu, depth):
-    """recursionDepth is an unbounded Int upstream (Integrators.hs:18-20).  Up to 4 the (w_k, D_k) stack of the fused
+    """recursionDepth is an unbounded Int upstream (Integrators.hs:18-20).  Up to 3 the (w_k, D_k) stack of the fused
     kernels lives in LDS; beyond that three levels do and the rest sit in a global array (43 is where the all-LDS layout
     stopped launching, 300 is past the 8-bit level count the stream form once had)."""
     img, ref = assert_parity(scenes.scene_fixed(96, 64).with_(depth=depth))

@@ -601,7 +601,7 @@ int yahr_ctx_render(yahr_ctx *c, int32_t row0, int32_t row1, const yahr_render_o
     // slices would not fit the budget (an eighth of the free memory, at most 8 GiB) is cut into several launches.
     rp.lds_levels = c->ds.depth <= YD_LDS_DEPTH ? c->ds.depth : YD_LDS_LEVELS;
     const size_t extra = (size_t)(c->ds.depth - rp.lds_levels);
-    if (extra > 0 && regroup) { set_error("the ray-regrouping diagnostics build keeps its level stack in LDS: recursion depth <= 4 only"); return YAHR_E_ARG; }
+    if (extra > 0 && regroup) { set_error("the ray-regrouping diagnostics build keeps its level stack in LDS: recursion depth <= 3 only"); return YAHR_E_ARG; }
     int chunk = n_blocks;
     if (extra > 0) {
       const size_t per_block = extra * 6 * 64 * sizeof(float);

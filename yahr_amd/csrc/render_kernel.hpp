@@ -71,7 +71,13 @@ struct RParams {
 };
 // Scenes of recursion depth <= YD_LDS_DEPTH keep the whole radiance stack in LDS (1.5 KiB per level and wavefront);
 // deeper ones keep YD_LDS_LEVELS levels there (4.5 KiB: room for 32 wavefronts per CU) and the rest in the spill.
-#define YD_LDS_DEPTH 4
+// Depth 4 already pays for the spill: 6 KiB per wavefront left room for 26 wavefronts per CU where the packet kernel asks
+// for 28 (pseudo-bunny 3840x2160 x 64 spp, depth 4: 92.9 ms per frame with three levels in LDS + one spilled, 93.8 all-LDS).
+#ifdef YD_LDS_DEPTH_OVERRIDE
+#define YD_LDS_DEPTH YD_LDS_DEPTH_OVERRIDE
+#else
+#define YD_LDS_DEPTH 3
+#endif
 #define YD_LDS_LEVELS 3
 
 // Wavefront ("stream") form of the same path, for scenes whose secondary rays are incoherent: the radiance

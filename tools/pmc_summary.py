@@ -6,10 +6,21 @@ import collections, csv, glob, re, sys
 root = sys.argv[1]
 all_grids = "--all-grids" in sys.argv
 rows = collections.defaultdict(list)          # (kernel, counter) -> [(grid, value)]
+
+
+def counted(name):
+    """is this the collect_stats instantiation?  k_render<MODE, STATS, WPB, DEEP>, k_stream_primary<STATS>, k_stream_level<MODE, STATS>"""
+    m = re.search(r"(k_\w+)<([^>]*)>", name.split("(")[0])
+    if not m:
+        return False
+    args = [a.strip() for a in m.group(2).split(",")]
+    pos = {"k_render": 1, "k_stream_primary": 0, "k_stream_level": 1}.get(m.group(1))
+    return pos is not None and pos < len(args) and args[pos] == "true"
+
 for f in sorted(glob.glob(root + "/**/*_counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"]
-        if not (("k_render" in name or "k_stream" in name or "k_sort" in name) and "true" not in name.split("(")[0]):
+        if not (("k_render" in name or "k_stream" in name or "k_sort" in name) and not counted(name)):
             continue
         short = re.sub(r"^void ", "", name.split("(")[0])
         rows[(short, r["Counter_Name"])].append((int(r.get("Grid_Size", 0) or 0), float(r["Counter_Value"])))

@@ -13,7 +13,8 @@ import yahr_amd
 from yahr_amd import scenes
 
 TR = {"lane": yahr_amd.TRAVERSE_LANE, "packet": yahr_amd.TRAVERSE_PACKET, "hybrid": yahr_amd.TRAVERSE_HYBRID,
-      "auto": yahr_amd.TRAVERSE_AUTO, "stream": yahr_amd.TRAVERSE_STREAM}
+      "auto": yahr_amd.TRAVERSE_AUTO, "stream": yahr_amd.TRAVERSE_STREAM, "stack": yahr_amd.TRAVERSE_STACK,
+      "hybrid_stack": yahr_amd.TRAVERSE_HYBRID_STACK, "ordered": yahr_amd.TRAVERSE_ORDERED}
 
 def _no_lights(d):
     d.lights = []
@@ -31,7 +32,8 @@ desc = {"bunny": lambda: scenes.pseudo_bunny(), "spheres": lambda: scenes.sphere
         "bunny4": lambda: scenes.pseudo_bunny(depth=4),
         "tris": lambda: scenes.random_tris(), "tris200k": lambda: scenes.random_tris(200000, bvh_depth=16),
         "tris_d1": lambda: scenes.random_tris(depth=1),            # primary + shadow rays
-        "tris_primary": lambda: _no_lights(scenes.random_tris(depth=1))}[a.scene]()
+        "tris_primary": lambda: _no_lights(scenes.random_tris(depth=1)),
+        "tris_refl": lambda: _no_lights(scenes.random_tris(depth=2))}[a.scene]()        # primary + reflection rays, no shadow rays
 scene = desc.to_scene().build()
 ctx = yahr_amd.Context(scene, 0)
 MAXF = 32
@@ -42,8 +44,9 @@ for v in a.variants:
     parts = v.split(":")
     name, tr, tun = parts[0], parts[1], parts[2]
     frames = int(parts[3]) if len(parts) > 3 else 1
+    walker = TR[parts[4]] if len(parts) > 4 else 0          # walker of the stream form's secondary rays (diagnostics)
     assert frames <= MAXF
-    variants.append((name, yahr_amd.make_opts(traverse=TR[tr], tuning=int(tun), spp=a.spp, frames=frames)))
+    variants.append((name, yahr_amd.make_opts(traverse=TR[tr], tuning=int(tun), spp=a.spp, frames=frames, stream_walker=walker)))
 times = {n: [] for n, _ in variants}
 ref = None
 for r in range(a.rounds + 2):

@@ -17,6 +17,11 @@
 
 using yahr::set_error;
 
+#define YD_PASS_STREAMS_MAX 4              /* internal streams (each with its own queue set) the passes of the wavefront form may be dealt to */
+#ifndef YD_PASS_STREAMS
+#define YD_PASS_STREAMS 2
+#endif
+
 void yahr_internal_counters_to_stats(const unsigned long long *h, yahr_stats *out);
 
 struct yahr_ctx {
@@ -39,12 +44,12 @@ struct yahr_ctx {
   // wavefront ("stream") form: path queues, per-level results, queue lengths (allocated on first use, grown on demand)
   // ... in TWO sets: the passes of a launch (frames of a batch, bands of a frame) are dealt to two internal streams, each
   // with its own queues, so that the tail of one pass -- a few long wavefronts on a mostly idle chip -- overlaps the next
-  void *d_stream[2] = {nullptr, nullptr}; size_t stream_bytes[2] = {0, 0};
-  hipStream_t pass_stream[2] = {nullptr, nullptr};
-  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+  void *d_stream[YD_PASS_STREAMS_MAX] = {}; size_t stream_bytes[YD_PASS_STREAMS_MAX] = {};
+  hipStream_t pass_stream[YD_PASS_STREAMS_MAX] = {};
+  hipEvent_t ev_fork = nullptr, ev_join[YD_PASS_STREAMS_MAX] = {};
   // fused kernels, scenes deeper than YD_LDS_LEVELS: the upper levels of the radiance stack (allocated on first use)
   void *d_spill = nullptr; size_t spill_bytes = 0;
-  unsigned *d_qcount[2] = {nullptr, nullptr}; int qcount_n[2] = {0, 0};
+  unsigned *d_qcount[YD_PASS_STREAMS_MAX] = {}; int qcount_n[YD_PASS_STREAMS_MAX] = {};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
   double upload_ms = 0;
@@ -365,7 +370,7 @@ void yahr_ctx_destroy(yahr_ctx *c) {
   (void)hipFree(c->d_nodes); (void)hipFree(c->d_prims); (void)hipFree(c->d_normals); (void)hipFree(c->d_mats);
   (void)hipFree(c->d_lights); (void)hipFree(c->d_ctr); (void)hipFree(c->d_windows); (void)hipFree(c->d_cold); (void)hipFree(c->d_pairs);
   (void)hipFree(c->d_cams); (void)hipFree(c->d_row_order); (void)hipFree(c->d_spill);
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < YD_PASS_STREAMS_MAX; ++k) {
     (void)hipFree(c->d_stream[k]); (void)hipFree(c->d_qcount[k]);
     if (c->pass_stream[k]) (void)hipStreamDestroy(c->pass_stream[k]);
     if (c->ev_join[k]) (void)hipEventDestroy(c->ev_join[k]);
@@ -423,7 +428,8 @@ static size_t stream_fixed_bytes(int depth) { return sizeof(unsigned) * YD_SORT_
 static int stream_band_rows(yahr_ctx *c, int n_local_rows, int tile_h, int spp, int depth) {
   size_t fr = 0, tot = 0;
   if (hipMemGetInfo(&fr, &tot) != hipSuccess) return 0;
-  const size_t held = c->stream_bytes[0] + c->stream_bytes[1];
+  size_t held = 0;
+  for (int k = 0; k < YD_PASS_STREAMS_MAX; ++k) held += c->stream_bytes[k];
   size_t budget = (fr + held) / 8;
   const size_t cap = (size_t)16 << 30;
   if (budget > cap) budget = cap;
@@ -475,8 +481,8 @@ static int ensure_stream(yahr_ctx *c, int set, size_t n_samples, int depth, SPar
 }
 
 // the two internal streams of the wavefront form and the events that fork them off the caller's stream and join them back
-static int ensure_pass_streams(yahr_ctx *c) {
-  for (int k = 0; k < 2; ++k) {
+static int ensure_pass_streams(yahr_ctx *c, int n) {
+  for (int k = 0; k < n; ++k) {
     if (!c->pass_stream[k]) HIP_TRY(hipStreamCreateWithFlags(&c->pass_stream[k], hipStreamNonBlocking));
     if (!c->ev_join[k]) HIP_TRY(hipEventCreateWithFlags(&c->ev_join[k], hipEventDisableTiming));
   }
@@ -604,21 +610,24 @@ int yahr_ctx_render(yahr_ctx *c, int32_t row0, int32_t row1, const yahr_render_o
       // queues of its own, forked off the caller's stream and joined back into it (events: legal inside a graph capture):
       // 1 M triangles x 16 spp 33.4 -> 32.2 ms per frame of a batch, 200 k triangles 9.2 -> 8.4.  Passes write disjoint
       // rows / frames and only add to the counters, so which stream runs which cannot change a result.
-      const bool two = frames * n_bands >= 2 && !std::getenv("YAHR_ONE_PASS_STREAM");
-      SParams sps[2] = {};
+      int ns = YD_PASS_STREAMS;
+      if (const char *e = std::getenv("YAHR_PASS_STREAMS")) ns = std::max(1, std::min(YD_PASS_STREAMS_MAX, std::atoi(e)));
+      ns = std::min(ns, frames * n_bands);
+      const bool two = ns >= 2;
+      SParams sps[YD_PASS_STREAMS_MAX] = {};
       int rc = ensure_stream(c, 0, band_samples, c->ds.depth, sps[0]); if (rc) return rc;
-      hipStream_t ps[2] = {st, st};
+      hipStream_t ps[YD_PASS_STREAMS_MAX] = {st, st, st, st};
       if (two) {
-        if ((rc = ensure_stream(c, 1, band_samples, c->ds.depth, sps[1]))) return rc;
-        if ((rc = ensure_pass_streams(c))) return rc;
+        for (int k = 1; k < ns; ++k) if ((rc = ensure_stream(c, k, band_samples, c->ds.depth, sps[k]))) return rc;
+        if ((rc = ensure_pass_streams(c, ns))) return rc;
         HIP_TRY(hipEventRecord(c->ev_fork, st));
-        for (int k = 0; k < 2; ++k) { ps[k] = c->pass_stream[k]; HIP_TRY(hipStreamWaitEvent(ps[k], c->ev_fork, 0)); }
+        for (int k = 0; k < ns; ++k) { ps[k] = c->pass_stream[k]; HIP_TRY(hipStreamWaitEvent(ps[k], c->ev_fork, 0)); }
       }
       rp.frames = 1; rp.cams = nullptr; rp.frame_stride = 0;
       int pass = 0, err = YAHR_OK;
       for (int f = 0; f < frames && !err; ++f) {
         for (int lv0 = 0; lv0 < rp.n_local_rows && !err; lv0 += band_rows, ++pass) {
-          const int k = two ? (pass & 1) : 0;
+          const int k = two ? (pass % ns) : 0;
           SParams &q = sps[k];
           q.cam = cams ? cams + f : c->ds.cold;
           q.lv0 = lv0;
@@ -636,7 +645,7 @@ int yahr_ctx_render(yahr_ctx *c, int32_t row0, int32_t row1, const yahr_render_o
         }
       }
       if (two)                                                             // join, also after an error: nothing stays forked
-        for (int k = 0; k < 2; ++k)
+        for (int k = 0; k < ns; ++k)
           if (hipEventRecord(c->ev_join[k], ps[k]) != hipSuccess || hipStreamWaitEvent(st, c->ev_join[k], 0) != hipSuccess) {
             if (!err) { set_error("joining the pass streams failed"); err = YAHR_E_HIP; }
           }

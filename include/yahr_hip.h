@@ -190,9 +190,10 @@ enum {
                                   surviving paths compacted into a queue in HBM between launches (ballot + prefix),
                                   so every wavefront of a level starts with 64 live rays, and the level launches run in
                                   Morton order of the hit points (counting sort on the device); same image, same
-                                  counters.  Needs 141 + 32 x depth bytes of device memory per sample of a band of
+                                  counters.  Needs 142 + 32 x depth bytes of device memory per sample of a band of
                                   rows (allocated inside the context on first use; bands are sized to an eighth of
-                                  the free memory) */
+                                  the free memory), twice that when a launch holds several passes -- frames of a batch,
+                                  bands of a frame -- which then overlap on two internal streams */
   YAHR_TRAVERSE_STACK = 5,     /* STREAM whose secondary rays run on the stack walker: every lane on its own over child-PAIR
                                   records (one fetch = both children's boxes) with an LDS stack of pending right siblings;
                                   the reference's tests in the reference's order (same image, same counters) */

@@ -128,6 +128,15 @@ def test_deep_recursion_in_several_launches(gpu, monkeypatch):
             assert st[k] == ost[k], (k, m)
     batch = ctx.render(traverse=yahr_amd.TRAVERSE_PACKET, frames=3).cpu().numpy()
     assert all(np.array_equal(bits(batch[f]), bits(whole)) for f in range(3))
+    # ... the reference's squareBatches tiling, row shards and supersampling on the deep kernel, chunked as well
+    ref_tiles = ctx.render(traverse=yahr_amd.TRAVERSE_PACKET, tiles=yahr_amd.TILES_REFERENCE).cpu().numpy()
+    assert np.array_equal(bits(ref_tiles), bits(whole))
+    from yahr_amd import shard_global_rows
+    for sh in range(3):
+        part = ctx.render(traverse=yahr_amd.TRAVERSE_HYBRID, n_shards=3, shard=sh, strip_rows=5).cpu().numpy()
+        assert np.array_equal(bits(part), bits(whole[shard_global_rows(64, 3, sh, 5)])), sh
+    ref4, _ = oracle_render(d, 4, 7)
+    assert outside_tol(ctx.render(traverse=yahr_amd.TRAVERSE_LANE, spp=4, seed=7).cpu().numpy(), ref4) == 0
     rays = np.stack([OracleScene.from_desc(d).build().camera_ray(u, v) for u in range(0, 96, 12) for v in range(0, 64, 8)])
     assert outside_tol(ctx.radiance(rays, yahr_amd.TRAVERSE_PACKET)[None], np.stack([OracleScene.from_desc(d).build().radiance(r) for r in rays])[None]) == 0
     ctx.close()

@@ -233,3 +233,14 @@ def test_cli_without_gpu_fails_loudly(tmp_path):
     # the Blender add-on's argv shape (render_engine.py:44-47)
     r = run_cli(str(good), str(tmp_path / "o.png"), "-p", "eval", "+RTS", "-N4")
     assert r.returncode == 1 and "no HIP device" in r.stderr and not (tmp_path / "o.png").exists()
+
+
+def test_committed_profile_belongs_to_the_committed_kernels():
+    """bench.py quotes `roofline.frac` from instruction counts of a rocprofv3 PMC profile kept under profiles/ -- only while
+    the fingerprint stored with it (kernel sources + compiler flag lines, yahr_amd/srchash.py) is the tree's.  This test is
+    the reminder to re-profile (tools/final_profiles.sh on the GPU box) after the last kernel change of a round."""
+    import json
+    from yahr_amd.srchash import kernel_source_hash
+    prof = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
+    assert prof["workload"] == "bunny" and prof["valu_insts_per_frame"] > 1e8
+    assert prof["kernel_source_sha256"] == kernel_source_hash(), "kernel sources changed after the profile was taken: re-profile"

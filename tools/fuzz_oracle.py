@@ -1,5 +1,5 @@
 """One-off: tests/test_gpu_parity.py's oracle comparison (pixels within 1e-4 rel + 1e-6, every counter exactly equal, the
-four forms bit-identical) on many more seeded random scenes than the suite holds.
+six forms bit-identical) on many more seeded random scenes than the suite holds.
 usage: fuzz_oracle.py [first seed] [number of seeds]"""
 import os
 import sys
@@ -19,7 +19,7 @@ for seed in range(first, first + count):
     d = random_scene_desc(seed)
     try:
         T.assert_parity(d)
-        T.assert_parity(d, modes=[T.yahr_amd.TRAVERSE_AUTO, T.yahr_amd.TRAVERSE_STREAM], spp=4, seed=seed)
+        T.assert_parity(d, modes=[T.yahr_amd.TRAVERSE_AUTO, T.yahr_amd.TRAVERSE_STREAM, T.yahr_amd.TRAVERSE_HYBRID_STACK], spp=4, seed=seed)
     except AssertionError as e:
         bad += 1
         print(f"seed {seed}: {e}", flush=True)

@@ -182,9 +182,9 @@ int32_t yahr_n_batches(int32_t num_threads, int32_t width, int32_t height);
 typedef struct yahr_ctx yahr_ctx;
 
 enum {
-  YAHR_TRAVERSE_AUTO = 0,      /* chosen per scene (yahr_ctx_create) and launch: PACKET below 100 k primitives; from there
-                                  on STREAM once a frame holds enough samples (3 M; 2 M on trees with leaves of more
-                                  than 16 primitives), else the fused PACKET or, for big thin trees, HYBRID kernel --
+  YAHR_TRAVERSE_AUTO = 0,      /* chosen per scene (yahr_ctx_create) and launch: PACKET below 150 k primitives; from there
+                                  on STREAM once a frame holds enough samples (3 M; 2 M on trees of 400 k primitives and
+                                  more with leaves of more than 16), else the fused PACKET or, for big thin trees, HYBRID kernel --
                                   a policy derived from a sweep (profiles/r03_auto_sweep*.csv) */
   YAHR_TRAVERSE_LANE = 1,      /* every lane walks the node array on its own (vector loads) */
   YAHR_TRAVERSE_PACKET = 2,    /* the wavefront walks the union of its lanes' paths (scalar node loads) */

@@ -20,14 +20,14 @@ sizes = [int(x) for x in os.environ.get("SWEEP_N", "50000,200000,1000000,4000000
 print("triangles,bvh_depth,nodes,largest_leaf,spp," + ",".join(n for n, _ in FORMS) + ",best", file=out, flush=True)
 st = torch.cuda.current_stream()
 for n in sizes:
-    for depth in (16, 20):
+    for depth in [int(x) for x in os.environ.get("SWEEP_DEPTHS", "16,20").split(",")]:
         d = scenes.random_tris(n, 1920, 1080, depth=2, bvh_depth=depth)
         scene = d.to_scene().build()
         a = scene.arrays()
         leaf = a["node_b"] >= 0
         ctx = yahr_amd.Context(scene, 0)
         buf = torch.zeros((1080, 1920, 3), device="cuda:0")
-        for spp in (1, 4, 16, 64):
+        for spp in [int(x) for x in os.environ.get("SWEEP_SPP", "1,4,16,64").split(",")]:
             row = []
             for name, mode in FORMS:
                 o = yahr_amd.make_opts(traverse=mode, spp=spp)

@@ -207,7 +207,7 @@ bool build_pairs(const yahr_scene *s, std::vector<yahr_node> &halves, int &level
 
 // AUTO policy, from a sweep, not from the benchmark scenes: random triangles 50 k .. 4 M x BVH depth 16 / 20 x 1 / 4 / 16 /
 // 64 spp at 1080p in every form (tools/auto_sweep.py, table in profiles/r03_auto_sweep.csv; ms per frame).  What it says:
-//   * below ~100 k primitives the packet walker wins at every sample count (50 k: 0.73 / 1.47 / 4.13 / 14.2 ms against
+//   * below ~150 k primitives the packet walker wins at every sample count (50 k: 0.73 / 1.47 / 4.13 / 14.2 ms against
 //     1.80 / 1.85 / 4.09 / 17.2 in the wavefront form): tiny trees, the union of 64 paths stays small;
 //   * from 200 k primitives on the wavefront ("stream") form wins as soon as a launch holds enough paths to fill its level
 //     launches -- 4 spp at 1080p (8 M samples) everywhere (200 k: 4.6 against 5.2; 1 M: 14.3 against 20.6 .. 46.7; 4 M:
@@ -222,13 +222,18 @@ bool build_pairs(const yahr_scene *s, std::vector<yahr_node> &halves, int &level
 struct AutoPolicy { int fused; size_t stream_min_samples; int secondary; };
 AutoPolicy auto_policy_for(const yahr_scene *s) {
   AutoPolicy p{TRAV_PACKET, (size_t)-1, TRAV_ADAPTIVE};                  // (size_t)-1: never the wavefront form
-  if (s->n_prims < 100000) return p;
+  // (a second sweep filled the gaps -- 100 k / 300 k / 500 k primitives x depth 14 / 16 / 20 x 1 / 2 / 4 spp,
+  // profiles/r03_auto_sweep_gaps.csv: at 100 k the packet walker still wins up to 8 M samples (1.5-2.9 ms against 3.5),
+  // at 300 k the wavefront form from 4 M samples on but not yet at 2 M even on fat leaves (7.5 against 8.2), at 500 k it
+  // does: 13.0 against 15.8)
+  if (s->n_prims < 150000) return p;
   int32_t biggest = 0;
   for (int32_t i = 0; i < s->n_nodes; ++i)
     if (s->nodes[i].b >= 0 && s->nodes[i].a > biggest) biggest = s->nodes[i].a;
   const bool fat = biggest > 16;
   p.fused = (!fat && s->n_nodes > 300000) ? TRAV_ADAPTIVE : TRAV_PACKET;
-  p.stream_min_samples = fat ? ((size_t)2 << 20) - 65536 : (size_t)3 << 20;   // fat: one 1080p frame at 1 spp is enough
+  // fat leaves and 400 k primitives or more: one 1080p frame at 1 spp is enough
+  p.stream_min_samples = (fat && s->n_prims >= 400000) ? ((size_t)2 << 20) - 65536 : (size_t)3 << 20;
   p.secondary = fat ? TRAV_ADAPT_STACK : TRAV_ADAPTIVE;
   return p;
 }

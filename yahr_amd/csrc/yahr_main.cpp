@@ -7,7 +7,7 @@
 // chose a CPU scheduling strategy there and all select the HIP path here -- plus the explicit `hip`.
 // `+RTS ... -RTS` (appended by the Blender add-on, render_engine.py:44-47) is accepted; -N<k> is echoed
 // in the status line.  Exit status: 0 on success, 1 on any error with the message on stderr, like an
-// uncaught Haskell exception.  Environment: YAHR_DEVICES=<n> limits the GPUs used (default: all),
+// uncaught Haskell exception.  Environment: YAHR_DEVICES=<n> renders on n GPUs (default: one),
 // YAHR_LENIENT=1 accepts the stale bundled scene.yahrr dialect, YAHR_SPP=<n> supersampling extension.
 #include <chrono>
 #include <cstdio>
@@ -79,7 +79,10 @@ int main(int argc, char **argv) {
   const double ms_load = since(t_start);               // read + parse + expand + BVH build + flatten
   int n_dev = yahr_device_count();
   if (n_dev < 1) { yahr_scene_free(hs); return die("no HIP device available (this build has no CPU path)"); }
-  if (const char *e = std::getenv("YAHR_DEVICES")) { int want = std::atoi(e); if (want >= 1 && want < n_dev) n_dev = want; }
+  // One process renders ONE image: a second GPU costs a second HIP context and a second copy of the scene (tens of
+  // milliseconds each) before it has traced a ray, more than any frame of the BASELINE configs takes on one GPU (1 ms ..
+  // 93 ms).  So one GPU unless YAHR_DEVICES=<n> asks for more (row strips over n GPUs, one peer-DMA gather: yahr_multi).
+  { int want = 1; if (const char *e = std::getenv("YAHR_DEVICES")) want = std::atoi(e); if (want < 1) want = 1; if (want < n_dev) n_dev = want; }
 
   yahr_render_opts opts; yahr_default_opts(&opts);
   if (const char *e = std::getenv("YAHR_SPP")) { int s = std::atoi(e); if (s >= 1) opts.spp = s; }

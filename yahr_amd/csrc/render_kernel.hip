@@ -16,13 +16,20 @@
 //                    `v_cmp` + vcc!=0 decides "descend" for the wave, and a per-lane `wake` index
 //                    (the skip link of the subtree the lane missed) masks lanes that are not inside
 //                    the current subtree.  Preorder indices only grow, so a lane is active iff wake<=i.
+//   * stack walker:  (wavefront form only, opt-in / AUTO on fat-leaf trees) every lane on its own over child-PAIR
+//                    records with an LDS stack of pending right siblings; still the reference's order -- and
+//                    an opt-in variant that visits the nearer child first (stack_loop)
 // Equal-t ties, t<=tMax acceptance, back-face culling and NaN behaviour therefore match the oracle
 // bit for bit; shadow rays stop at the first accepted primitive (same Bool as Rays.hs:49-54).
 //
-// What bounds this kernel (rocprofv3 PMC, profiles/): not bytes -- the whole scene sits in L2/MALL and the
-// frame moves ~75 MB over HBM -- but the serial instruction chain of the heaviest wavefronts: a wave issues
-// one instruction per ~4 clocks, and a tile over dense geometry walks thousands of dependent node/primitive
-// steps.  So the code is shaped for FEW INSTRUCTIONS PER STEP:
+// Kernels: k_render<MODE, STATS, WPB, DEEP> (fused: one wavefront renders its tile's pixels to the end; DEEP = recursion
+// depth > 3, upper levels of the radiance stack in global memory), and the wavefront ("stream") form k_stream_primary /
+// k_stream_level / k_stream_resolve with the counting sort k_sort_* in between (paths compacted between bounces).
+//
+// What bounds the fused kernel (rocprofv3 PMC, profiles/): not bytes -- the whole scene sits in L2/MALL and a
+// frame moves ~33 MB over HBM, 25 of them the image -- but vector-instruction issue and, for a lone frame, the serial
+// chains of the heaviest wavefronts: a wave issues one instruction per ~4 clocks, and a tile over dense geometry walks
+// thousands of dependent node/primitive steps.  So the code is shaped for FEW INSTRUCTIONS PER STEP:
 //   * each walker is instantiated once per kernel (radiance is a wave-uniform state machine with a single
 //     traversal call site; first-hit mode is a run-time flag; one pixel loop for all tilings / sample counts);
 //   * the fast build carries no counters at all (ray and test counts come from the collect_stats build);

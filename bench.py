@@ -103,10 +103,24 @@ def algorithmic_bytes(st, n_lights, n_pixels):
             + (32 + 24 * n_lights) * st["shaded_hits"] + 12 * n_pixels)
 
 
-def cpu_baseline(desc, cores, spp=1, min_cpu_seconds=10.0):
+def parity_of(gpu, cpu):
+    """the parity check of the same run -- per channel |g - c| <= 1e-4 * max(|g|, |c|) + 1e-6"""
+    g, c = gpu.astype(np.float64), cpu.astype(np.float64)
+    err = np.abs(g - c)
+    tol = 1e-4 * np.maximum(np.abs(g), np.abs(c)) + 1e-6
+    rel = err / np.maximum(np.maximum(np.abs(g), np.abs(c)), 1e-30)
+    return dict(pixels=int(g.shape[0] * g.shape[1]), pixels_outside_tolerance=int((err > tol).any(axis=2).sum()),
+                max_rel_err=float(rel[err > 1e-6].max()) if (err > 1e-6).any() else 0.0, max_abs_err=float(err.max()),
+                bit_identical_pixels=int((gpu.view(np.uint32) == cpu.view(np.uint32)).all(axis=2).sum()),
+                tolerance="|g - c| <= 1e-4 max(|g|, |c|) + 1e-6 per channel")
+
+
+def cpu_baseline(desc, cores, spp=1, min_cpu_seconds=10.0, gpu_rows=None):
     """The oracle (CPU restatement of the reference, kind "port": the Haskell reference cannot be built here)
     timed on the host cores over the same workload: whole frames (scene camera), repeated until ~min_cpu_seconds
-    of CPU work (spp == 1), or a bounded sample of evenly spaced 8-row strips of one frame (supersampled)."""
+    of CPU work (spp == 1), or a bounded sample of evenly spaced 8-row strips of one frame (supersampled).
+    gpu_rows(r0, r1) -> the HIP path's rows of the same frame (scene camera): what the oracle has rendered anyway is
+    compared with them, the parity check of the same run.  Returns (baseline, oracle stats or None, parity or None)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_py                      # the checker, timed beside the product; never part of the product path
     osc = oracle_py.OracleScene.from_desc(desc).build()
@@ -116,10 +130,13 @@ def cpu_baseline(desc, cores, spp=1, min_cpu_seconds=10.0):
         strips = list(range(0, h - 7, 8))
         order = [strips[(i * 37) % len(strips)] for i in range(len(strips))]      # spread over the image
         prim, done = 0, 0
+        cpu_strips, gpu_strips = [], []
         for r0 in order:
             t0 = time.perf_counter()
-            _, st = osc.render_rows(r0, r0 + 8, spp=spp, seed=0, threads=cores)
+            rows, st = osc.render_rows(r0, r0 + 8, spp=spp, seed=0, threads=cores)
             wall += time.perf_counter() - t0
+            if gpu_rows is not None:
+                cpu_strips.append(rows); gpu_strips.append(gpu_rows(r0, r0 + 8))
             rays += st["primary_rays"] + st["reflection_rays"] + st["shadow_rays"]
             prim += st["primary_rays"]
             done += 1
@@ -128,17 +145,20 @@ def cpu_baseline(desc, cores, spp=1, min_cpu_seconds=10.0):
         return dict(value=round(rays / wall / 1e6, 3), unit="Mrays/s", cores=cores, kind="port",
                     sample=f"{done} strips of 8 rows (of {len(strips)}) spread over one frame at {spp} spp, render only, "
                            f"{wall:.2f} s wall on {cores} threads (one thread per image row)",
-                    mpixels_per_s=round(prim / spp / wall / 1e6, 4)), None
+                    mpixels_per_s=round(prim / spp / wall / 1e6, 4)), None, \
+            (parity_of(np.concatenate(gpu_strips), np.concatenate(cpu_strips)) if gpu_strips else None)
+    img = None
     while wall * cores < min_cpu_seconds and reps < 50:
         t0 = time.perf_counter()
-        _, st = osc.render(threads=cores)
+        img, st = osc.render(threads=cores)
         wall += time.perf_counter() - t0
         reps += 1
         rays += st["primary_rays"] + st["reflection_rays"] + st["shadow_rays"]
     return dict(value=round(rays / wall / 1e6, 3), unit="Mrays/s", cores=cores, kind="port",
                 sample=f"{reps} full frame(s) of the same workload (scene camera), render only (scene build excluded), "
                        f"{wall:.2f} s wall on {cores} threads over the reference's squareBatches tiles",
-                mpixels_per_s=round(reps * st["primary_rays"] / wall / 1e6, 3)), st
+                mpixels_per_s=round(reps * st["primary_rays"] / wall / 1e6, 3)), st, \
+        (parity_of(gpu_rows(0, img.shape[0]), img) if gpu_rows is not None and img is not None else None)
 
 
 def load_profile(workload):
@@ -444,8 +464,14 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             cores = min(16, os.cpu_count() or 1)
-            cb, ost = cpu_baseline(desc, cores, spp)
+            def gpu_rows(r0, r1):               # the HIP path's rows of the scene camera's frame, same sampler and seed
+                t = torch.zeros((r1 - r0, w, 3), dtype=torch.float32, device=dev)
+                ctx.render_into(t.data_ptr(), r0, r1, yahr_amd.make_opts(traverse=trav, spp=spp, seed=0), stream.cuda_stream)
+                torch.cuda.synchronize()
+                return t.cpu().numpy()
+            cb, ost, par = cpu_baseline(desc, cores, spp, gpu_rows=gpu_rows)
             out["cpu_baseline"] = cb
+            out["parity"] = par
             if ost is not None:
                 roof["algorithmic_bytes_reference_order_per_frame"] = algorithmic_bytes(ost, scene.n_lights, w * h)
         else:

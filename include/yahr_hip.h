@@ -267,6 +267,13 @@ int yahr_device_mem_info(int device, uint64_t *free_bytes, uint64_t *total_bytes
  * 0 disarms.  Used to check that no error path of this library leaks device memory. */
 void yahr_debug_fail_alloc(int32_t nth);
 
+/* Test hook (host only): the child-pair records of the stack walkers for this scene -- two yahr_node-shaped child records
+ * per interior node, in DFS order of the interior nodes: a leaf child as in `nodes`; an interior child with a = rank of
+ * its own pair and b = -1 - its DFS index.  Returns their number (0: the scene has none -- the root is a leaf, a box is
+ * not finite, or a node's box is not exactly the join of its children's) and copies at most `cap` of them to `out`;
+ * *levels = entries of the per-lane stack (depth of the deepest node). */
+int32_t yahr_debug_pair_records(const yahr_scene *scene, yahr_node *out, int32_t cap, int32_t *levels);
+
 /* Upload a flattened scene to `device` (index as seen by this process).  The context owns device memory. */
 int yahr_ctx_create(const yahr_scene *scene, int device, yahr_ctx **out);
 void yahr_ctx_destroy(yahr_ctx *ctx);

@@ -125,3 +125,56 @@ def test_concurrent_subtree_build_is_the_same_tree(split, monkeypatch):
         chunked = d.to_scene().build().arrays()
         for k in seq:
             assert np.ascontiguousarray(seq[k]).tobytes() == np.ascontiguousarray(chunked[k]).tobytes(), (k, p)
+
+
+def _pair_records(scene):
+    import ctypes as C
+    lv = C.c_int32()
+    n = yahr_amd.lib.yahr_debug_pair_records(scene.flat, None, 0, C.byref(lv))
+    if n == 0:
+        return None, 0
+    buf = np.zeros((n, 8), dtype=np.uint32)
+    assert yahr_amd.lib.yahr_debug_pair_records(scene.flat, buf.ctypes.data_as(C.c_void_p), n, C.byref(lv)) == n
+    return buf, lv.value
+
+
+@pytest.mark.parametrize("desc", [scenes.pseudo_bunny(16, 9), scenes.pseudo_bunny(16, 9, bvh_depth=3), scenes.spec_sphere_grid("SurfaceAreaHeuristic"),
+                                  scenes.random_tris(5000, 16, 9, bvh_depth=20), scenes.scene_fixed(16, 16)], ids=["bunny", "bunny3", "grid", "tris", "fixed"])
+def test_pair_records_of_the_stack_walkers(desc):
+    """The child-pair records (render_kernel.hpp: DPairs) the stack walkers run on, built on the host from the flattened
+    tree: one pair per interior node in DFS order of the interior nodes, the left child (node i + 1) and the right child
+    (the node behind the left subtree) side by side; leaf children as in the node array, interior children with the rank of
+    their own pair and -1 - their DFS index; every interior box exactly the join of its children's (what lets a popped
+    node re-derive its own box); stack levels = depth of the deepest node."""
+    scene = desc.to_scene().build()
+    a = scene.arrays()
+    halves, levels = _pair_records(scene)
+    na, nb = a["node_a"], a["node_b"]
+    inner = np.flatnonzero(nb < 0)
+    assert halves is not None and len(halves) == 2 * len(inner)
+    rank = {int(i): k for k, i in enumerate(inner)}
+    depth = {0: 0}
+    lo = halves[:, 0:3].view(np.float32); hi = halves[:, 4:7].view(np.float32)
+    ha = halves[:, 3].view(np.int32); hb = halves[:, 7].view(np.int32)
+    for i in map(int, inner):
+        left = i + 1
+        right = left + 1 if nb[left] >= 0 else int(na[left])
+        assert (int(na[right]) if nb[right] < 0 else right + 1) == int(na[i])          # the right subtree ends where node i's does
+        for side, c in ((0, left), (1, right)):
+            h = 2 * rank[i] + side
+            assert np.array_equal(lo[h].view(np.uint32), a["node_lo"][c].view(np.uint32)) and np.array_equal(hi[h].view(np.uint32), a["node_hi"][c].view(np.uint32))
+            if nb[c] >= 0:
+                assert ha[h] == na[c] and hb[h] == nb[c]
+            else:
+                assert ha[h] == rank[c] and hb[h] == -1 - c
+            depth[c] = depth[i] + 1
+        assert np.array_equal(a["node_lo"][i], np.minimum(a["node_lo"][left], a["node_lo"][right]))
+        assert np.array_equal(a["node_hi"][i], np.maximum(a["node_hi"][left], a["node_hi"][right]))
+    assert levels == max(depth.values())
+
+
+def test_scenes_without_pair_records():
+    """a root that is a leaf, an empty box (the null collider's) or a non-finite box: no pair records, the walkers use the node array"""
+    for d in (scenes.pseudo_bunny(16, 9, bvh_depth=0), scenes.scene_fixed(8, 8).with_(objects=[]),
+              scenes.scene_fixed(8, 8).with_(objects=scenes.scene_fixed(8, 8).objects + [("sphere", (0.0, 0.0, 0.0), float("inf"), "sphere")])):
+        assert _pair_records(d.to_scene().build())[0] is None

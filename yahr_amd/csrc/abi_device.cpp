@@ -296,6 +296,17 @@ int yahr_device_mem_info(int device, uint64_t *free_bytes, uint64_t *total_bytes
   return YAHR_OK;
 }
 
+// Test hook (host only, no device needed): the child-pair records the stack walkers would get for this scene.
+int32_t yahr_debug_pair_records(const yahr_scene *s, yahr_node *out, int32_t cap, int32_t *levels) {
+  if (levels) *levels = 0;
+  if (!s || s->n_nodes < 0 || (s->n_nodes && !s->nodes)) return 0;
+  std::vector<yahr_node> halves; int lv = 0;
+  if (!build_pairs(s, halves, lv)) return 0;
+  if (levels) *levels = lv;
+  if (out) std::memcpy(out, halves.data(), sizeof(yahr_node) * std::min((size_t)(cap > 0 ? cap : 0), halves.size()));
+  return (int32_t)halves.size();
+}
+
 void yahr_debug_fail_alloc(int32_t nth) { g_fail_alloc_countdown.store(nth > 0 ? nth : 0); }
 
 int32_t yahr_shard_rows(int32_t height, int32_t n_shards, int32_t shard, int32_t strip_rows) {

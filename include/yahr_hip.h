@@ -185,7 +185,12 @@ enum {
   YAHR_TRAVERSE_AUTO = 0,      /* chosen per scene (yahr_ctx_create) and launch: PACKET below 150 k primitives; from there
                                   on STREAM once a frame holds enough samples (3 M; 2 M on trees of 400 k primitives and
                                   more with leaves of more than 16), else the fused PACKET or, for big thin trees, HYBRID kernel --
-                                  a policy derived from a sweep (profiles/r03_auto_sweep*.csv) */
+                                  a policy derived from sweeps (profiles/r03_auto_sweep*.csv) for scenes
+                                  whose rays do NOT stay together (triangle soups).  Whether they do is measured: for
+                                  scenes of 150 k primitives and more yahr_ctx_create renders four 8-row strips with the
+                                  counted packet kernel; where its lanes are 30 % busy or more (tessellated meshes:
+                                  45-80 %, soups 5-20 %) AUTO never leaves the fused kernels
+                                  (profiles/r03_mesh_sweep.csv) */
   YAHR_TRAVERSE_LANE = 1,      /* every lane walks the node array on its own (vector loads) */
   YAHR_TRAVERSE_PACKET = 2,    /* the wavefront walks the union of its lanes' paths (scalar node loads) */
   YAHR_TRAVERSE_HYBRID = 3,    /* adaptive: a packet while the rays stay coherent, then every lane on its own */

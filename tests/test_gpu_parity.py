@@ -802,13 +802,13 @@ def test_error_paths_do_not_leak_device_memory(gpu):
     m.close()
     free0 = free_now()
     try:
-        for nth in range(1, 8):                                         # nodes, prims, normals, mats, lights, counters, cold
+        for nth in range(1, 9):                                         # nodes, prims, normals, mats, lights, counters, cold; the coherence probe's strip
             L.yahr_debug_fail_alloc(nth)
             with pytest.raises(yahr_amd.YahrError) as e:
                 yahr_amd.Context(scene, 0)
             assert e.value.code == -5, (nth, str(e.value))
             assert abs(free_now() - free0) <= slack, nth
-        L.yahr_debug_fail_alloc(8)                                      # beyond the last allocation: create succeeds
+        L.yahr_debug_fail_alloc(9)                                      # beyond the last allocation: create succeeds
         ctx = yahr_amd.Context(scene, 0)
         L.yahr_debug_fail_alloc(0)
         free1 = free_now()
@@ -826,12 +826,12 @@ def test_error_paths_do_not_leak_device_memory(gpu):
                     fn(arg)
                 assert e.value.code == -5
                 assert abs(free_now() - free1) <= slack, (fn.__name__, nth)
-        L.yahr_debug_fail_alloc(8)                                      # one-shot render: its image buffer (8th) fails
+        L.yahr_debug_fail_alloc(9)                                      # one-shot render: its image buffer (9th) fails
         with pytest.raises(yahr_amd.YahrError):
             yahr_amd.render_image(scene)
         assert abs(free_now() - free1) <= slack
-        # yahr_multi: its contexts (7 allocations each) and its buffer sets go through the same allocator
-        for nth in list(range(1, 15, 3)) + [15, 16, 17, 18, 19, 20]:
+        # yahr_multi: its contexts (8 allocations each) and its buffer sets go through the same allocator
+        for nth in list(range(1, 17, 3)) + [17, 18, 19, 20, 21, 22]:
             L.yahr_debug_fail_alloc(nth)
             with pytest.raises(yahr_amd.YahrError) as e:
                 yahr_amd.MultiContext(scene, 2, devices=[0, 0], gather=yahr_amd.GATHER_PEER)

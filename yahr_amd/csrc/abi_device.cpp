@@ -38,6 +38,8 @@ struct yahr_ctx {
   int *d_row_order = nullptr; int row_order_n = 0;
   int auto_mode = TRAV_PACKET;            // AUTO: the fused kernel's walker ...
   size_t auto_stream_min = (size_t)-1;    // ... and from how many samples per launch on the wavefront form instead
+  double probe_lanes = -1.0;              // lane utilisation of the packet walker measured by the probe of yahr_ctx_create (-1: not probed)
+  bool deep_thin = false;                 // more than 300 k nodes and at most 4 primitives per leaf on average
   int stream_secondary = TRAV_ADAPTIVE;   // walker of the secondary rays in the wavefront form (auto_policy_for)
   unsigned long long *d_ctr = nullptr;
   int4 *d_windows = nullptr; int n_windows = 0, n_chunks = 0, windows_w = 0, windows_h = 0;
@@ -219,18 +221,20 @@ bool build_pairs(const yahr_scene *s, std::vector<yahr_node> &halves, int &level
 //   * secondary rays of the wavefront form: on fat leaves the stack walker after the packet start is 5-10 % ahead of the
 //     skip-link lane walker (1 M, depth 16: 17.0 / 29.4 / 64.5 / 162 against 18.3 / 31.6 / 67.0 / 165), on thin leaves
 //     2-5 % behind (1 M, depth 20, 16 spp: 35.7 against 34.0).
-struct AutoPolicy { int fused; size_t stream_min_samples; int secondary; };
+struct AutoPolicy { int fused; size_t stream_min_samples; int secondary; bool deep_thin; };
 AutoPolicy auto_policy_for(const yahr_scene *s) {
-  AutoPolicy p{TRAV_PACKET, (size_t)-1, TRAV_ADAPTIVE};                  // (size_t)-1: never the wavefront form
+  AutoPolicy p{TRAV_PACKET, (size_t)-1, TRAV_ADAPTIVE, false};           // (size_t)-1: never the wavefront form
   // (a second sweep filled the gaps -- 100 k / 300 k / 500 k primitives x depth 14 / 16 / 20 x 1 / 2 / 4 spp,
   // profiles/r03_auto_sweep_gaps.csv: at 100 k the packet walker still wins up to 8 M samples (1.5-2.9 ms against 3.5),
   // at 300 k the wavefront form from 4 M samples on but not yet at 2 M even on fat leaves (7.5 against 8.2), at 500 k it
   // does: 13.0 against 15.8)
   if (s->n_prims < 150000) return p;
-  int32_t biggest = 0;
+  int32_t biggest = 0, n_leaves = 0;
   for (int32_t i = 0; i < s->n_nodes; ++i)
-    if (s->nodes[i].b >= 0 && s->nodes[i].a > biggest) biggest = s->nodes[i].a;
+    if (s->nodes[i].b >= 0) { ++n_leaves; if (s->nodes[i].a > biggest) biggest = s->nodes[i].a; }
   const bool fat = biggest > 16;
+  // a big tree whose TYPICAL leaf is thin (a mesh in a deep tree keeps one fat leaf -- the floor's -- and is thin otherwise)
+  p.deep_thin = s->n_nodes > 300000 && (int64_t)s->n_prims <= 4 * (int64_t)n_leaves;
   p.fused = (!fat && s->n_nodes > 300000) ? TRAV_ADAPTIVE : TRAV_PACKET;
   // fat leaves and 400 k primitives or more: one 1080p frame at 1 spp is enough
   p.stream_min_samples = (fat && s->n_prims >= 400000) ? ((size_t)2 << 20) - 65536 : (size_t)3 << 20;
@@ -370,12 +374,36 @@ int yahr_ctx_create(const yahr_scene *s, int device, yahr_ctx **out) {
   d.cold = (const DCold *)c->d_cold;
   d.n_nodes = s->n_nodes; d.n_prims = s->n_prims; d.n_mats = s->n_mats; d.n_lights = s->n_lights;
   d.depth = s->depth;
-  { const AutoPolicy ap = auto_policy_for(s); c->auto_mode = ap.fused; c->auto_stream_min = ap.stream_min_samples; c->stream_secondary = ap.secondary; }
+  { const AutoPolicy ap = auto_policy_for(s); c->auto_mode = ap.fused; c->auto_stream_min = ap.stream_min_samples; c->stream_secondary = ap.secondary; c->deep_thin = ap.deep_thin; }
   d.boxes_finite = 1;
   for (int32_t i = 0; i < s->n_nodes && d.boxes_finite; ++i)
     for (int k = 0; k < 3; ++k)
       if (!std::isfinite(s->nodes[i].lo[k]) || !std::isfinite(s->nodes[i].hi[k]) || !(s->nodes[i].lo[k] <= s->nodes[i].hi[k]))
         d.boxes_finite = 0;
+  // Is the wavefront form a candidate at all?  Then ask the scene how coherent its rays are: a probe render (four strips
+  // of 8 rows of the scene camera's frame, 1 spp, packet walker, counted build) yields the lane utilisation of the packet
+  // walker's node steps = box tests / (64 x wavefront node steps).  Triangle soups -- where compaction between bounces
+  // pays -- measure 0.05-0.20, tessellated meshes 0.45-0.80 (tools/coherence_probe.py; 16 rows or the whole frame give the
+  // same figure), and on meshes the packet walker beats the wavefront form 2-3x at every size and sample count tried
+  // (profiles/r03_mesh_sweep.csv: 2.2 M triangles x 16 spp 6.1 ms against 16.1), so AUTO keeps the wavefront form for
+  // scenes below 0.3.  Costs one small launch and a counter read-back here, where the scene is uploaded anyway.
+  if (c->auto_stream_min != (size_t)-1 && c->width > 0 && c->height > 0 && !std::getenv("YAHR_NO_COHERENCE_PROBE")) {
+    const int strip = std::min(8, c->height);
+    DevMem probe;
+    HIP_TRY(probe.alloc(sizeof(float) * 3 * (size_t)strip * (size_t)c->width));
+    yahr_render_opts po; yahr_default_opts(&po);
+    po.traverse = YAHR_TRAVERSE_PACKET; po.collect_stats = 1;
+    for (int k = 0; k < 4; ++k) {
+      const int r0 = std::min(c->height - strip, (int)((int64_t)c->height * (2 * k + 1) / 8) / 8 * 8);
+      if ((rc = yahr_ctx_render(c, r0 < 0 ? 0 : r0, (r0 < 0 ? 0 : r0) + strip, &po, probe.as<float>(), nullptr))) return rc;
+    }
+    yahr_stats ps;
+    rc = yahr_ctx_stats(c, &ps);                                // (synchronises; an unknown material met by the probe is not an error yet)
+    if (rc && rc != YAHR_E_MATERIAL) return rc;
+    c->timed = false;
+    c->probe_lanes = ps.wave_node_steps ? (double)ps.box_tests / (64.0 * (double)ps.wave_node_steps) : 1.0;
+    if (c->probe_lanes >= 0.3) { c->auto_stream_min = (size_t)-1; c->auto_mode = TRAV_PACKET; }
+  }
   *out = own.release();
   return YAHR_OK;
 }
@@ -577,6 +605,11 @@ int yahr_ctx_render(yahr_ctx *c, int32_t row0, int32_t row1, const yahr_render_o
     n_blocks *= rp.frames;
   }
   int mode = pick_mode(o.traverse, c->auto_mode);
+  // AUTO on a coherent scene (the probe of yahr_ctx_create): the packet walker -- except one sample per pixel through a
+  // deep tree of thin leaves, where neighbouring pixels' paths part near the leaves and the adaptive walker is ahead
+  // (1.1 M-triangle mesh, depth 20: 1.8 ms against 2.1; 2.2 M: 2.5 against 3.4; with 4 spp and more the samples of a
+  // pixel share a wavefront and the packet wins again: 2.6 against 2.9, 5.7 against 7.2)
+  if (o.traverse == YAHR_TRAVERSE_AUTO && c->probe_lanes >= 0.3 && c->deep_thin && o.spp == 1) mode = TRAV_ADAPTIVE;
   // AUTO: the wavefront form once a launch holds enough paths to fill its level launches (auto_policy_for)
   if (o.traverse == YAHR_TRAVERSE_AUTO &&
       (size_t)rp.n_local_rows * (size_t)c->width * (size_t)(o.spp > 0 ? o.spp : 1) >= c->auto_stream_min)   // (per frame: a batch is rendered frame by frame in that form)

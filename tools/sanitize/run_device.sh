@@ -8,7 +8,7 @@ import sys; sys.path[:0] = ["$ROOT"]
 from yahr_amd import scenes
 w = sys.argv[1]
 open(w + "/bunny.yahrr", "w").write(scenes.pseudo_bunny(203, 117, n_lon=48, n_lat=25, depth=3).to_text())
-open(w + "/soup.yahrr", "w").write(scenes.random_tris(40000, 160, 90, depth=6, bvh_depth=18).to_text())   # depth 6: level spill; 40 000: device BVH build
+open(w + "/soup.yahrr", "w").write(scenes.random_tris(160000, 160, 90, depth=6, bvh_depth=18).to_text())   # depth 6: level spill; 160 000: device BVH build, coherence probe of yahr_ctx_create
 PY
 SAN="-Xarch_host -fsanitize=address -Xarch_host -fsanitize=undefined -Xarch_host -fno-omit-frame-pointer"
 HF="--offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize $SAN -I$ROOT/include -I$SRC"

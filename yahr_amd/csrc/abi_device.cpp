@@ -605,11 +605,10 @@ int yahr_ctx_render(yahr_ctx *c, int32_t row0, int32_t row1, const yahr_render_o
     n_blocks *= rp.frames;
   }
   int mode = pick_mode(o.traverse, c->auto_mode);
-  // AUTO on a coherent scene (the probe of yahr_ctx_create): the packet walker -- except one sample per pixel through a
-  // deep tree of thin leaves, where neighbouring pixels' paths part near the leaves and the adaptive walker is ahead
-  // (1.1 M-triangle mesh, depth 20: 1.8 ms against 2.1; 2.2 M: 2.5 against 3.4; with 4 spp and more the samples of a
-  // pixel share a wavefront and the packet wins again: 2.6 against 2.9, 5.7 against 7.2)
-  if (o.traverse == YAHR_TRAVERSE_AUTO && c->probe_lanes >= 0.3 && c->deep_thin && o.spp == 1) mode = TRAV_ADAPTIVE;
+  // AUTO on a coherent scene (the probe of yahr_ctx_create): always the packet walker.  (One sample per pixel through a
+  // deep tree of thin leaves is the one case where the adaptive walker is ahead -- 1.1 M-triangle mesh, depth 20: 1.8 ms
+  // against 2.1; 2.2 M: 2.5 against 3.4 -- but its downside is not worth that: the same mesh inside a cloud of loose
+  // triangles takes 45 ms adaptive against 9.4 packet, the lane walker crawling through every fat leaf it meets.)
   // AUTO: the wavefront form once a launch holds enough paths to fill its level launches (auto_policy_for)
   if (o.traverse == YAHR_TRAVERSE_AUTO &&
       (size_t)rp.n_local_rows * (size_t)c->width * (size_t)(o.spp > 0 ? o.spp : 1) >= c->auto_stream_min)   // (per frame: a batch is rendered frame by frame in that form)

@@ -142,6 +142,45 @@ def test_deep_recursion_in_several_launches(gpu, monkeypatch):
     ctx.close()
 
 
+def test_frame_batch_beyond_one_grid(gpu, monkeypatch):
+    """A 1-D grid holds fewer than 2^32 work-items (2^26 wavefront-sized workgroups): a frame batch beyond that is rendered
+    as several launches of whole frames, the chunked launches of a deep scene are cut to it.  Here with the limit lowered
+    to 100 workgroups (YAHR_MAX_GRID_BLOCKS): the reference's tiling, the deep kernel and the diagnostics
+    builds, nine cameras, bit for bit against the same batch in one launch -- and a frame that does not fit is refused."""
+    d = scenes.scene_fixed(64, 40)
+    scene = d.to_scene().build()
+    ctx = yahr_amd.Context(scene, 0)
+    cams = [dict(d.camera, pos=(-4 + 0.5 * i, 3, 2), look=(0.4, -0.3 - 0.02 * i, 1)) for i in range(9)]
+    ctx.set_cameras([[c["imW"], c["imH"], c["focal"], *c["look"], *c["up"], *c["pos"]] for c in cams])
+    # (the launches that are 1-D grids: the reference's tiling and the diagnostics builds; row shards of wave tiles run as
+    # 3-D grids like whole frames and are here for contrast)
+    cases = [dict(tiles=yahr_amd.TILES_REFERENCE, n_batches=6), dict(tiles=yahr_amd.TILES_REFERENCE, n_batches=3, spp=4, seed=3),
+             dict(tuning=yahr_amd.TUNE_REGROUP), dict(tuning=yahr_amd.TUNE_XCD_BANDS), dict(tuning=yahr_amd.TUNE_CENTRE_FIRST),
+             dict(traverse=yahr_amd.TRAVERSE_LANE, tiles=yahr_amd.TILES_REFERENCE), dict(n_shards=2, shard=1, strip_rows=8)]
+    for kw in cases:
+        monkeypatch.delenv("YAHR_MAX_GRID_BLOCKS", raising=False)
+        one = ctx.render(frames=9, collect_stats=True, **kw).cpu().numpy()
+        st1 = ctx.stats()
+        monkeypatch.setenv("YAHR_MAX_GRID_BLOCKS", "100")
+        cut = ctx.render(frames=9, collect_stats=True, **kw).cpu().numpy()
+        st2 = ctx.stats()
+        assert one.any() and np.array_equal(bits(one), bits(cut)), kw
+        for k in ("primary_rays", "reflection_rays", "shadow_rays", "shaded_hits", "box_tests", "tri_tests", "sphere_tests"):
+            assert st1[k] == st2[k], (k, kw)
+    monkeypatch.setenv("YAHR_MAX_GRID_BLOCKS", "3")                          # one frame is 40 workgroups
+    with pytest.raises(yahr_amd.YahrError, match="too large"):
+        ctx.render(frames=2, tiles=yahr_amd.TILES_REFERENCE)
+    monkeypatch.delenv("YAHR_MAX_GRID_BLOCKS")
+    ctx.close()
+    # the deep kernel: its chunks (here cut by the grid limit, not by the memory budget)
+    dd = d.with_(depth=7)
+    ctx = yahr_amd.Context(dd.to_scene().build(), 0)
+    one = ctx.render(frames=3, n_shards=2, shard=0, strip_rows=8).cpu().numpy()
+    monkeypatch.setenv("YAHR_MAX_GRID_BLOCKS", "7")
+    assert np.array_equal(bits(one), bits(ctx.render(frames=3, n_shards=2, shard=0, strip_rows=8).cpu().numpy()))
+    ctx.close()
+
+
 @pytest.mark.parametrize("split", ["Midpoint", "SurfaceAreaHeuristic"])
 def test_spec_sphere_grid_image(gpu, split):
     assert_parity(scenes.spec_sphere_grid(split).with_camera(imW=96, imH=96))

@@ -731,9 +731,29 @@ int yahr_ctx_render(yahr_ctx *c, int32_t row0, int32_t row1, const yahr_render_o
       rp.tile_rows = rp.n_tiles / rp.tiles_x;
       if (rp.tile_rows <= 65535 && rp.tiles_x <= 65535) rp.grid3d = 1;
     }
-    for (int b0 = 0; b0 < n_blocks; b0 += chunk) {
-      rp.block0 = (unsigned)b0;
-      HIP_TRY(yahr_dev::launch_render(c->ds, rp, mode, regroup, std::min(chunk, n_blocks - b0), d_rgb, c->d_ctr, o.collect_stats != 0, st));
+    // A 1-D grid holds fewer than 2^32 work-items (the dispatch packet's grid size is 32 bits per dimension): 2^26 - 8
+    // wavefront-sized workgroups (a quarter of that in the regrouping build).  The 3-D grid is far from that in every dimension; the chunked launches of a deep scene
+    // are cut to it; any other launch beyond it is a frame batch (one 8192 x 8192 x 64 spp frame is 2^26 workgroups
+    // and refused below), which is rendered as several launches of whole frames.
+    int max_blocks = ((1 << 26) - 8) / (regroup ? 4 : 1);
+    if (const char *e = std::getenv("YAHR_MAX_GRID_BLOCKS")) { const int v = std::atoi(e); if (v > 0) max_blocks = std::min(max_blocks, v); }   // tests
+    if (extra > 0) chunk = std::min(chunk, max_blocks);
+    if (!rp.grid3d && extra == 0 && n_blocks > max_blocks) {
+      const int frames = rp.frames, per_frame = n_blocks / frames;
+      if (per_frame > max_blocks) { set_error("image too large for one launch: more than 2^32 samples in a frame"); return YAHR_E_ARG; }
+      const int fpl = max_blocks / per_frame;                                // frames per launch
+      const DCold *cams = rp.cams;
+      for (int f0 = 0; f0 < frames; f0 += fpl) {
+        rp.frames = std::min(fpl, frames - f0);
+        rp.cams = cams ? cams + f0 : nullptr;
+        HIP_TRY(yahr_dev::launch_render(c->ds, rp, mode, regroup, per_frame * rp.frames, d_rgb + (size_t)f0 * rp.frame_stride, c->d_ctr,
+                                        o.collect_stats != 0, st));
+      }
+    } else {
+      for (int b0 = 0; b0 < n_blocks; b0 += chunk) {
+        rp.block0 = (unsigned)b0;
+        HIP_TRY(yahr_dev::launch_render(c->ds, rp, mode, regroup, std::min(chunk, n_blocks - b0), d_rgb, c->d_ctr, o.collect_stats != 0, st));
+      }
     }
   }
   HIP_TRY(hipEventRecord(c->ev1, st));

@@ -219,32 +219,35 @@ __global__ __launch_bounds__(BT) void k_scatter(int n, int nb, int level, const 
 // box of a leaf: foldl join empty over its primitives' boxes in leaf order (Culling.hs:52-54, AABBs.hs:24-27)
 __global__ void k_leaf_boxes(int n_nodes, BNode *nodes, const float4 *__restrict__ items, const float *__restrict__ boxes) {
   // one wavefront per node: lanes fold contiguous runs in order, then the runs are joined in lane order (the join of two
-  // folds is the fold of the concatenation: min keeps its left operand on a tie, max its right one)
-  const int j = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-  if (j >= n_nodes) return;
-  BNode &nd = nodes[j];
-  if (nd.left >= 0) return;
-  const float inf = __builtin_huge_valf();
-  float lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf};
-  const int per = (nd.count + 63) / 64;
-  for (int t = lane * per, e = min(nd.count, (lane + 1) * per); t < e; ++t) {
-    const int id = __float_as_int(items[nd.first + t].w);
-    const float *b = boxes + 6 * (size_t)id;
+  // folds is the fold of the concatenation: min keeps its left operand on a tie, max its right one).  A grid-stride loop:
+  // one wavefront per node in one launch would be 64 work-items per node, and a grid holds fewer than 2^32 of them (the
+  // trees of 34 M primitives and more have over 2^26 nodes).
+  const int lane = threadIdx.x & 63, stride = (int)(gridDim.x * (blockDim.x >> 6));
+  for (int j = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); j < n_nodes; j += stride) {      // (j is wave-uniform)
+    BNode &nd = nodes[j];
+    if (nd.left >= 0) continue;
+    const float inf = __builtin_huge_valf();
+    float lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf};
+    const int per = (nd.count + 63) / 64;
+    for (int t = lane * per, e = min(nd.count, (lane + 1) * per); t < e; ++t) {
+      const int id = __float_as_int(items[nd.first + t].w);
+      const float *b = boxes + 6 * (size_t)id;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { lo[k] = hmin(lo[k], b[k]); hi[k] = hmax(hi[k], b[3 + k]); }
+      for (int k = 0; k < 3; ++k) { lo[k] = hmin(lo[k], b[k]); hi[k] = hmax(hi[k], b[3 + k]); }
+    }
+    if (nd.count > 1) {
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const float ol = __shfl_down(lo[k], off, 64), oh = __shfl_down(hi[k], off, 64);
+          if (lane + off < 64) { lo[k] = hmin(lo[k], ol); hi[k] = hmax(hi[k], oh); }
+        }
+    }
+    if (lane == 0)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { nd.lo[k] = lo[k]; nd.hi[k] = hi[k]; }
   }
-  if (nd.count > 1) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1)
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const float ol = __shfl_down(lo[k], off, 64), oh = __shfl_down(hi[k], off, 64);
-        if (lane + off < 64) { lo[k] = hmin(lo[k], ol); hi[k] = hmax(hi[k], oh); }
-      }
-  }
-  if (lane == 0)
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { nd.lo[k] = lo[k]; nd.hi[k] = hi[k]; }
 }
 
 __global__ void k_bottom_up(int n0, int n1, BNode *nodes) {
@@ -317,24 +320,26 @@ bool device_build_bvh(const float *boxes, int32_t n, int max_depth, std::vector<
   hipEvent_t e0 = nullptr, e1 = nullptr;
   struct Ev { hipEvent_t &a, &b; ~Ev() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); } } evs{e0, e1};
 #define BV(expr) do { if ((expr) != hipSuccess) { (void)hipGetLastError(); return fail(std::string(#expr) + " failed"); } } while (0)
+  // (every launch is checked by itself: a later successful launch must not be able to hide a refused one)
+#define LAUNCH(...) do { hipLaunchKernelGGL(__VA_ARGS__); BV(hipGetLastError()); } while (0)
   BV(hipEventCreate(&e0)); BV(hipEventCreate(&e1));
   BV(hipMemcpy(d_boxes, boxes, sizeof(float) * 6 * (size_t)n, hipMemcpyHostToDevice));
   BV(hipMemset(d_cnt, 0, sizeof(int) * 2));
   BV(hipEventRecord(e0, nullptr));
-  hipLaunchKernelGGL(k_items, dim3(nb), dim3(BT), 0, nullptr, n, d_boxes, it[0], sg[0]);
-  hipLaunchKernelGGL(k_root, dim3(1), dim3(1), 0, nullptr, d_nodes, n, d_cnt);
+  LAUNCH(k_items, dim3(nb), dim3(BT), 0, nullptr, n, d_boxes, it[0], sg[0]);
+  LAUNCH(k_root, dim3(1), dim3(1), 0, nullptr, d_nodes, n, d_cnt);
   std::vector<int> lvl_start{0, 1};                                      // node ids of level l: [lvl_start[l], lvl_start[l + 1])
   int cur = 0;
   for (int level = 0; level < max_depth; ++level) {
     const int n0 = lvl_start[(size_t)level], n1 = lvl_start[(size_t)level + 1];
     if (n1 == n0) break;
     const int gb = (n1 - n0 + 255) / 256;
-    hipLaunchKernelGGL(k_bounds, dim3(nb), dim3(BT), 0, nullptr, n, level, it[cur], sg[cur], d_nodes);
-    hipLaunchKernelGGL(k_decide, dim3(gb), dim3(256), 0, nullptr, n0, n1, level, d_nodes);
-    hipLaunchKernelGGL(k_scan_local, dim3(nb), dim3(BT), 0, nullptr, n, level, it[cur], sg[cur], d_nodes, d_local, d_tot);
-    hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(BT), 0, nullptr, nb, d_tot);
-    hipLaunchKernelGGL(k_children, dim3(gb), dim3(256), 0, nullptr, n0, n1, level, n, nb, d_nodes, d_local, d_tot, d_cnt, d_cnt + 1);
-    hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(BT), 0, nullptr, n, nb, level, it[cur], sg[cur], d_nodes, d_local, d_tot, it[cur ^ 1], sg[cur ^ 1]);
+    LAUNCH(k_bounds, dim3(nb), dim3(BT), 0, nullptr, n, level, it[cur], sg[cur], d_nodes);
+    LAUNCH(k_decide, dim3(gb), dim3(256), 0, nullptr, n0, n1, level, d_nodes);
+    LAUNCH(k_scan_local, dim3(nb), dim3(BT), 0, nullptr, n, level, it[cur], sg[cur], d_nodes, d_local, d_tot);
+    LAUNCH(k_scan_tops, dim3(1), dim3(BT), 0, nullptr, nb, d_tot);
+    LAUNCH(k_children, dim3(gb), dim3(256), 0, nullptr, n0, n1, level, n, nb, d_nodes, d_local, d_tot, d_cnt, d_cnt + 1);
+    LAUNCH(k_scatter, dim3(nb), dim3(BT), 0, nullptr, n, nb, level, it[cur], sg[cur], d_nodes, d_local, d_tot, it[cur ^ 1], sg[cur ^ 1]);
     cur ^= 1;
     int h[2];
     BV(hipMemcpy(h, d_cnt, sizeof h, hipMemcpyDeviceToHost));            // nodes so far; did a partition misbehave?
@@ -344,17 +349,17 @@ bool device_build_bvh(const float *boxes, int32_t n, int max_depth, std::vector<
     if (h[0] == n1) break;                                               // nothing was split on this level
   }
   const int total = lvl_start.back();
-  hipLaunchKernelGGL(k_leaf_boxes, dim3((unsigned)(((size_t)total * 64 + 255) / 256)), dim3(256), 0, nullptr, total, d_nodes, it[cur], d_boxes);
+  LAUNCH(k_leaf_boxes, dim3((unsigned)std::min<size_t>(((size_t)total + 3) / 4, (size_t)1 << 20)), dim3(256), 0, nullptr, total, d_nodes, it[cur], d_boxes);
   for (int l = (int)lvl_start.size() - 2; l >= 0; --l) {
     const int n0 = lvl_start[(size_t)l], n1 = lvl_start[(size_t)l + 1];
-    if (n1 > n0) hipLaunchKernelGGL(k_bottom_up, dim3((n1 - n0 + 255) / 256), dim3(256), 0, nullptr, n0, n1, d_nodes);
+    if (n1 > n0) LAUNCH(k_bottom_up, dim3((n1 - n0 + 255) / 256), dim3(256), 0, nullptr, n0, n1, d_nodes);
   }
   for (size_t l = 0; l + 1 < lvl_start.size(); ++l) {
     const int n0 = lvl_start[l], n1 = lvl_start[l + 1];
-    if (n1 > n0) hipLaunchKernelGGL(k_top_down, dim3((n1 - n0 + 255) / 256), dim3(256), 0, nullptr, n0, n1, d_nodes);
+    if (n1 > n0) LAUNCH(k_top_down, dim3((n1 - n0 + 255) / 256), dim3(256), 0, nullptr, n0, n1, d_nodes);
   }
-  hipLaunchKernelGGL(k_emit, dim3((total + 255) / 256), dim3(256), 0, nullptr, total, d_nodes, d_out);
-  hipLaunchKernelGGL(k_order, dim3(nb), dim3(BT), 0, nullptr, n, it[cur], d_order);
+  LAUNCH(k_emit, dim3((total + 255) / 256), dim3(256), 0, nullptr, total, d_nodes, d_out);
+  LAUNCH(k_order, dim3(nb), dim3(BT), 0, nullptr, n, it[cur], d_order);
   BV(hipGetLastError());
   BV(hipEventRecord(e1, nullptr));
   std::vector<yahr_node> out_nodes((size_t)total);
@@ -363,6 +368,7 @@ bool device_build_bvh(const float *boxes, int32_t n, int max_depth, std::vector<
   BV(hipMemcpy(out_order.data(), d_order, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
   float ms = 0;
   if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess && device_ms) *device_ms = ms;
+#undef LAUNCH
 #undef BV
   nodes.swap(out_nodes);
   order.swap(out_order);

@@ -656,6 +656,21 @@ def test_random_scenes_against_the_oracle(gpu, seed):
     assert_parity(d, modes=[yahr_amd.TRAVERSE_AUTO], spp=4, seed=seed)
 
 
+def test_many_lights_and_materials(gpu):
+    """37 point lights (37 shadow rays per hit, summed in list order, Integrators.hs:33-36) and 500 materials, one per
+    sphere, duplicate ids among them (Data.Map.fromList: the later one wins, main.hs:57): every form against the oracle"""
+    rng = np.random.default_rng(4242)
+    mats = [scenes._mat("m%d" % (i if i % 50 else 0), (0, 0, 0), tuple(rng.uniform(0.1, 0.9, 3)), tuple(rng.uniform(0.0, 0.6, 3)),
+                        float(rng.choice([1, 4, 10, 40, 200]))) for i in range(500)]
+    ids = sorted({m["id"] for m in mats})
+    objs = [("sphere", tuple(rng.uniform(-5, 5, 3) + (0, 0, 12)), float(rng.uniform(0.15, 0.5)), ids[i % len(ids)]) for i in range(500)]
+    objs += scenes.scene_fixed(8, 8).objects[-1:]                                   # the floor
+    lights = [(tuple(rng.uniform(-9, 9, 3) + (0, 8, 6)), tuple(rng.uniform(5, 40, 3))) for _ in range(37)]
+    d = scenes.scene_fixed(88, 56).with_(materials=scenes.scene_fixed(8, 8).materials + mats, lights=lights, objects=objs, depth=3)
+    assert_parity(d)
+    assert_parity(d, modes=[yahr_amd.TRAVERSE_AUTO, yahr_amd.TRAVERSE_STREAM], spp=4, seed=5)
+
+
 @pytest.mark.parametrize("bvh_depth", [0, 3, 16])
 def test_extreme_operands_walkers_agree(gpu, bvh_depth):
     """Adversarial operands for the packet walker's shortcuts (NaN-free slab form, tMax = -1 for sleeping lanes, the

@@ -656,6 +656,52 @@ def test_random_scenes_against_the_oracle(gpu, seed):
     assert_parity(d, modes=[yahr_amd.TRAVERSE_AUTO], spp=4, seed=seed)
 
 
+def test_degenerate_deep_tree(gpu):
+    """Primitives centred at x = 2^-k exactly (y = z = 0): every midpoint split peels ONE primitive off, so the tree is a
+    chain as deep as `BVH depth` allows (here ~100 levels; the benchmark trees stop near 20).  Every form against the oracle
+    -- the stack walkers decline trees deeper than 48 levels and walk the node array instead -- and the device build
+    against the host's."""
+    objs = []
+    for k in range(100):
+        x, r = 2.0 ** -k, 2.0 ** -(k + 3)
+        if k % 3 == 0:
+            objs.append(("sphere", (x, 0.0, 0.0), r, "sphere"))
+        else:
+            objs.append(("triangle", (x - r, -r, 0.0), (x, r, 0.0), (x + r, -r, 0.0), (0, 0, -1), (0, 0, -1), (0, 0, -1), "sphere"))
+    base = scenes.scene_fixed(72, 48)
+    d = base.with_(objects=objs + base.objects[-1:], bvh_depth=120, depth=3).with_camera(pos=(0.35, 0.1, -1.6), look=(0.0, -0.05, 1.0))
+    host = d.to_scene().set_builder(yahr_amd.BUILDER_HOST).build()
+    a = host.arrays()
+    n, deepest = len(a["node_a"]), 0
+    level = np.zeros(n + 1, dtype=np.int64)
+    for i in range(n):
+        if a["node_b"][i] < 0:
+            left = i + 1
+            right = left + 1 if a["node_b"][left] >= 0 else a["node_a"][left]
+            level[left] = level[right] = level[i] + 1
+            deepest = max(deepest, int(level[left]))
+    assert deepest >= 95, deepest
+    dev = d.to_scene().set_builder(yahr_amd.BUILDER_DEVICE).build()
+    assert _same_flat_scene(a, dev.arrays()) is None
+    assert_parity(d)
+    assert_parity(d, modes=[yahr_amd.TRAVERSE_AUTO, yahr_amd.TRAVERSE_STREAM, yahr_amd.TRAVERSE_STACK], spp=4, seed=2)
+    # rays aimed at primitive k walk the chain down to level ~k: closest and first hit, every walker, and the oracle
+    rays = np.array([[0.0, 0.02, -1.0, 2.0 ** -k * f, -0.02, 1.0, 1e6] for k in range(100) for f in (1.0, 0.9375, 1.0625, 1.5)], dtype=np.float32)
+    ctx = yahr_amd.Context(dev, 0)
+    pl, tl = ctx.trace(rays, yahr_amd.TRAVERSE_LANE)
+    ol = ctx.occluded(rays, yahr_amd.TRAVERSE_LANE)
+    assert len(set(pl[pl >= 0].tolist())) > 60                              # most of the chain is hit by some ray
+    for mode in [yahr_amd.TRAVERSE_PACKET, yahr_amd.TRAVERSE_HYBRID] + STACK_MODES:
+        ps, ts = ctx.trace(rays, mode)
+        assert np.array_equal(pl, ps) and np.array_equal(bits(tl), bits(ts)), mode
+        assert np.array_equal(ol, ctx.occluded(rays, mode)), mode
+    osc = OracleScene.from_desc(d).build()
+    for i in range(len(rays)):
+        w, t = osc.intersect(rays[i])
+        assert w == pl[i] and (w < 0 or np.float32(t).view(np.uint32) == tl[i].view(np.uint32)), i
+    ctx.close()
+
+
 def test_many_lights_and_materials(gpu):
     """37 point lights (37 shadow rays per hit, summed in list order, Integrators.hs:33-36) and 500 materials, one per
     sphere, duplicate ids among them (Data.Map.fromList: the later one wins, main.hs:57): every form against the oracle"""

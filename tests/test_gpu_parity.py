@@ -8,6 +8,7 @@ Bar (BASELINE.json north_star): every pixel within 1e-4 relative.  What is actua
 At BASELINE.json's full sizes (1920x1080, ~70k triangles) the checks are size-independent properties:
 idempotence, walker-independence, tile-decomposition independence, shard assembly, exact linearity in the
 light spectrum (scaling by a power of two), plus oracle parity (the oracle finishes 1080p in seconds)."""
+import ctypes
 import json
 import math
 import os
@@ -926,9 +927,21 @@ def test_error_paths_do_not_leak_device_memory(gpu):
                     fn(arg)
                 assert e.value.code == -5
                 assert abs(free_now() - free1) <= slack, (fn.__name__, nth)
-        L.yahr_debug_fail_alloc(9)                                      # one-shot render: its image buffer (9th) fails
-        with pytest.raises(yahr_amd.YahrError):
-            yahr_amd.render_image(scene)
+        # one-shot render: no coherence probe (64 x 36 samples can never reach the wavefront form), so its image buffer is
+        # the 8th allocation; both one-shot entry points
+        for nth in (3, 8):
+            L.yahr_debug_fail_alloc(nth)
+            with pytest.raises(yahr_amd.YahrError) as e:
+                yahr_amd.render_image(scene)
+            assert e.value.code == -5 and abs(free_now() - free1) <= slack, nth
+            L.yahr_debug_fail_alloc(nth)
+            out = np.zeros((scene.height, scene.width, 3), dtype=np.float32)
+            o = yahr_amd.make_opts()
+            rc = L.yahr_render_multi(scene.flat, 1, ctypes.byref(o), out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), None)
+            assert rc == -5 and abs(free_now() - free1) <= slack, nth
+        L.yahr_debug_fail_alloc(9)                                      # beyond its last allocation: the one-shot call succeeds
+        yahr_amd.render_image(scene)
+        L.yahr_debug_fail_alloc(0)
         assert abs(free_now() - free1) <= slack
         # yahr_multi: its contexts (8 allocations each) and its buffer sets go through the same allocator
         for nth in list(range(1, 17, 3)) + [17, 18, 19, 20, 21, 22]:

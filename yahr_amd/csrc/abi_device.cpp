@@ -8,6 +8,8 @@
 #include <atomic>
 #include <cmath>
 #include <cstdlib>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -329,11 +331,20 @@ int32_t yahr_shard_global_row(int32_t local, int32_t n_shards, int32_t shard, in
   return (k * n_shards + shard) * strip_rows + (local - k * strip_rows);
 }
 
-int yahr_ctx_create(const yahr_scene *s, int device, yahr_ctx **out) {
+// samples_hint: the largest launch (rows x width x spp of one frame) this context will ever be asked for under AUTO, when the
+// caller knows it (the one-shot calls do); SIZE_MAX otherwise.  It only decides whether the coherence probe below is worth
+// running: the probe settles a choice that AUTO makes from `auto_stream_min` samples on.
+static int ctx_create_impl(const yahr_scene *s, int device, yahr_ctx **out, size_t samples_hint) {
   if (!out) { set_error("null argument"); return YAHR_E_ARG; }
   *out = nullptr;
+  // YAHR_TIMING=1: the phases of this call on stderr (wall clock; diagnostics of the command line's start-up cost)
+  const bool timing = std::getenv("YAHR_TIMING") && std::atoi(std::getenv("YAHR_TIMING")) != 0;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
+  auto t_phase = now();
   int rc = check_scene(s);
   if (rc != YAHR_OK) return rc;
+  const double ms_check = ms_since(t_phase);
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev == 0) { set_error("no HIP device available (libyahr_hip has no CPU fallback)"); return YAHR_E_NODEVICE; }
@@ -347,6 +358,8 @@ int yahr_ctx_create(const yahr_scene *s, int device, yahr_ctx **out) {
   CtxOwner own(new yahr_ctx());                           // every return below destroys it, except the last
   yahr_ctx *c = own.c;
   c->device = device; c->width = s->width; c->height = s->height;
+  const double ms_device = ms_since(t_phase) - ms_check;
+  t_phase = now();
   ScopedEvent u0, u1;
   HIP_TRY(hipEventCreate(&u0.e)); HIP_TRY(hipEventCreate(&u1.e));
   HIP_TRY(hipEventRecord(u0.e, nullptr));
@@ -362,6 +375,8 @@ int yahr_ctx_create(const yahr_scene *s, int device, yahr_ctx **out) {
   HIP_TRY(hipEventSynchronize(u1.e));
   float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, u0.e, u1.e)); c->upload_ms = ms;
   HIP_TRY(hipEventCreate(&c->ev0)); HIP_TRY(hipEventCreate(&c->ev1));
+  const double ms_upload = ms_since(t_phase);
+  t_phase = now();
   DCold cold{};
   cold.mats = (const float4 *)c->d_mats; cold.lights = (const float4 *)c->d_lights;
   camera_origin(s->cam_tf, cold.origin);
@@ -387,7 +402,10 @@ int yahr_ctx_create(const yahr_scene *s, int device, yahr_ctx **out) {
   // same figure), and on meshes the packet walker beats the wavefront form 2-3x at every size and sample count tried
   // (profiles/r03_mesh_sweep.csv: 2.2 M triangles x 16 spp 6.1 ms against 16.1), so AUTO keeps the wavefront form for
   // scenes below 0.3.  Costs one small launch and a counter read-back here, where the scene is uploaded anyway.
-  if (c->auto_stream_min != (size_t)-1 && c->width > 0 && c->height > 0 && !std::getenv("YAHR_NO_COHERENCE_PROBE")) {
+  const double ms_policy = ms_since(t_phase);
+  t_phase = now();
+  if (c->auto_stream_min != (size_t)-1 && samples_hint >= c->auto_stream_min && c->width > 0 && c->height > 0 &&
+      !std::getenv("YAHR_NO_COHERENCE_PROBE")) {
     const int strip = std::min(8, c->height);
     DevMem probe;
     HIP_TRY(probe.alloc(sizeof(float) * 3 * (size_t)strip * (size_t)c->width));
@@ -404,9 +422,16 @@ int yahr_ctx_create(const yahr_scene *s, int device, yahr_ctx **out) {
     c->probe_lanes = ps.wave_node_steps ? (double)ps.box_tests / (64.0 * (double)ps.wave_node_steps) : 1.0;
     if (c->probe_lanes >= 0.3) { c->auto_stream_min = (size_t)-1; c->auto_mode = TRAV_PACKET; }
   }
+  if (timing)
+    std::fprintf(stderr, "yahr-hip timing: yahr_ctx_create: validate %.1f ms, device query %.1f ms, allocate + upload %.1f ms (%.1f MB), "
+                         "policy scan %.1f ms, coherence probe %.1f ms\n", ms_check, ms_device, ms_upload,
+                 ((double)s->n_nodes * sizeof(yahr_node) + (double)s->n_prims * (sizeof(yahr_prim) + sizeof(yahr_prim_normals))) / 1e6,
+                 ms_policy, ms_since(t_phase));
   *out = own.release();
   return YAHR_OK;
 }
+
+int yahr_ctx_create(const yahr_scene *s, int device, yahr_ctx **out) { return ctx_create_impl(s, device, out, (size_t)-1); }
 
 void yahr_ctx_destroy(yahr_ctx *c) {
   if (!c) return;
@@ -894,11 +919,16 @@ int yahr_ctx_camera_rays(yahr_ctx *c, int32_t n, const float *uv, float *rays) {
 int yahr_render_rows(const yahr_scene *scene, int32_t row0, int32_t row1, int device,
                      const yahr_render_opts *opts, float *rgb_out, yahr_stats *stats) {
   if (!rgb_out) { set_error("null output"); return YAHR_E_ARG; }
+  if (!scene) { set_error("null scene"); return YAHR_E_ARG; }
   yahr_ctx *c = nullptr;
-  int rc = yahr_ctx_create(scene, device, &c);
-  if (rc) return rc;
   yahr_render_opts o; if (opts) o = *opts; else yahr_default_opts(&o);
   int32_t rows = (o.n_shards > 1) ? yahr_shard_rows(scene->height, o.n_shards, o.shard, o.strip_rows) : (row1 - row0);
+  // one-shot: this is the only launch the context will ever see, so the coherence probe (a counted launch: ~20 ms, most of
+  // it the scratch arena such a build needs) runs only if AUTO could take the wavefront form for it at all
+  const size_t samples = (o.traverse == YAHR_TRAVERSE_AUTO && rows > 0 && scene->width > 0)
+                             ? (size_t)rows * (size_t)scene->width * (size_t)(o.spp > 0 ? o.spp : 1) : 0;
+  int rc = ctx_create_impl(scene, device, &c, samples);
+  if (rc) return rc;
   size_t bytes = sizeof(float) * 3 * (size_t)(rows > 0 ? rows : 0) * (size_t)scene->width;
   float *d_rgb = nullptr;
   auto fail = [&](int code) { if (d_rgb) (void)hipFree(d_rgb); yahr_ctx_destroy(c); return code; };

@@ -25,6 +25,9 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -463,11 +466,30 @@ int yahr_render_multi(const yahr_scene *scene, int n_devices, const yahr_render_
   yahr_multi *m = nullptr;
   // one-shot: the peer-DMA transport -- a communicator (and loading the 570 MB RCCL library) costs more than the one
   // frame it would carry; the long-lived yahr_multi object is where RCCL pays
+  const bool timing = std::getenv("YAHR_TIMING") && std::atoi(std::getenv("YAHR_TIMING")) != 0;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
+  const auto t0 = now();
+  // One device, one frame: the plain one-shot call.  (A yahr_multi object brings two streams of its own per device -- on
+  // this runtime a stream's first use costs ~8 ms, its hardware queue -- and buffers for an exchange that does not happen.)
+  if (n_devices == 1 && (!opts || (opts->frames <= 1 && opts->tiles == YAHR_TILES_WAVE))) {
+    yahr_render_opts o; if (opts) o = *opts; else yahr_default_opts(&o);
+    o.n_shards = 1; o.shard = 0;
+    int rc1 = yahr_render_rows(scene, 0, scene->height, 0, &o, rgb_out, stats);
+    if (timing) std::fprintf(stderr, "yahr-hip timing: yahr_render_multi on one device: %.1f ms (create, render, download, destroy)\n", ms_since(t0));
+    return rc1;
+  }
   int rc = yahr_multi_create(scene, n_devices, nullptr, n_devices > 1 ? YAHR_GATHER_PEER : YAHR_GATHER_AUTO, opts ? opts->strip_rows : 8, &m);
   if (rc) return rc;
+  const double ms_create = ms_since(t0);
+  const auto t1 = now();
   rc = yahr_multi_render(m, opts, rgb_out, stats);
+  const double ms_render = ms_since(t1);
+  const auto t2 = now();
   std::string keep = rc ? yahr_last_error() : "";
   yahr_multi_destroy(m);
+  if (timing) std::fprintf(stderr, "yahr-hip timing: yahr_render_multi: create %.1f ms, render + gather + download %.1f ms, destroy %.1f ms\n",
+                           ms_create, ms_render, ms_since(t2));
   if (rc) set_error(keep);
   return rc;
 }

@@ -356,7 +356,8 @@ void yahr_pinned_free(void *p);
 int yahr_multi_transport(const yahr_multi *m);           /* YAHR_GATHER_RCCL / _PEER / _NONE actually in use */
 double yahr_multi_last_gather_ms(const yahr_multi *m);   /* device time of the last frame's exchange + placement */
 void yahr_multi_destroy(yahr_multi *m);
-/* one-shot: create + render + destroy (peer-DMA transport: no communicator is set up for a single frame) */
+/* one-shot: create + render + destroy (peer-DMA transport: no communicator is set up for a single frame; one device and
+ * one frame: exactly yahr_render_rows over the whole image on device 0) */
 int yahr_render_multi(const yahr_scene *scene, int n_devices, const yahr_render_opts *opts,
                       float *rgb_out, yahr_stats *stats_or_null);
 

@@ -108,11 +108,12 @@ def parity_of(gpu, cpu):
     g, c = gpu.astype(np.float64), cpu.astype(np.float64)
     err = np.abs(g - c)
     tol = 1e-4 * np.maximum(np.abs(g), np.abs(c)) + 1e-6
-    rel = err / np.maximum(np.maximum(np.abs(g), np.abs(c)), 1e-30)
+    mag = np.maximum(np.abs(g), np.abs(c))
+    big = mag >= 1e-3                                  # relative error where a relative error means something
     return dict(pixels=int(g.shape[0] * g.shape[1]), pixels_outside_tolerance=int((err > tol).any(axis=2).sum()),
-                max_rel_err=float(rel[err > 1e-6].max()) if (err > 1e-6).any() else 0.0, max_abs_err=float(err.max()),
+                max_rel_err=float((err[big] / mag[big]).max()) if big.any() else 0.0, max_abs_err=float(err.max()),
                 bit_identical_pixels=int((gpu.view(np.uint32) == cpu.view(np.uint32)).all(axis=2).sum()),
-                tolerance="|g - c| <= 1e-4 max(|g|, |c|) + 1e-6 per channel")
+                tolerance="|g - c| <= 1e-4 max(|g|, |c|) + 1e-6 per channel; max_rel_err over channels of magnitude >= 1e-3")
 
 
 def cpu_baseline(desc, cores, spp=1, min_cpu_seconds=10.0, gpu_rows=None):

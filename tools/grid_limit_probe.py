@@ -25,3 +25,17 @@ for tiles, name in ((yahr_amd.TILES_REFERENCE, "reference tiling (1-D grid)"), (
     print(f"{name}: {frames} frames in one call, {dt:.2f} s, frames bit-identical to a lone frame: {same} of {frames}; non-black {float((one > 0).float().mean()):.3f}", flush=True)
     del out
 ctx.close()
+# more than 2^31 workgroups in one call (3840x2160 x 64 spp: one pixel per wavefront, 8.3 M workgroups per frame, x 260 frames)
+d = scenes.spheres8(3840, 2160)
+ctx = yahr_amd.Context(d.to_scene().build(), 0)
+for tiles, name, frames in ((yahr_amd.TILES_WAVE, "wave tiles (3-D grid)", 260), (yahr_amd.TILES_REFERENCE, "reference tiling (1-D grid)", 20)):
+    one = ctx.render(tiles=tiles, spp=64, seed=1)
+    t = time.perf_counter()
+    out = ctx.render(frames=frames, tiles=tiles, spp=64, seed=1)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t
+    same = sum(int(torch.equal(out[f].view(torch.int32), one.view(torch.int32))) for f in range(frames))
+    print(f"3840x2160 x 64 spp, {name}: {frames} frames in one call ({frames * 8.2944:.0f} M workgroups if one pixel per wavefront), {dt:.2f} s, "
+          f"frames bit-identical to a lone frame: {same} of {frames}", flush=True)
+    del out
+ctx.close()

@@ -626,9 +626,8 @@ int yahr_ctx_render(yahr_ctx *c, int32_t row0, int32_t row1, const yahr_render_o
   if (rp.frames > 1) {
     if (c->n_cams != 0 && c->n_cams < rp.frames) { set_error("fewer cameras set than frames requested"); return YAHR_E_ARG; }
     rp.cams = c->n_cams ? c->d_cams : nullptr;
-    if ((int64_t)n_blocks * rp.frames > 0x7fffffffLL) { set_error("frame batch too large for one grid"); return YAHR_E_ARG; }
-    n_blocks *= rp.frames;
   }
+  const int per_frame = n_blocks;                                            // workgroups of one frame; a launch holds whole frames
   int mode = pick_mode(o.traverse, c->auto_mode);
   // AUTO on a coherent scene (the probe of yahr_ctx_create): always the packet walker.  (One sample per pixel through a
   // deep tree of thin leaves is the one case where the adaptive walker is ahead -- 1.1 M-triangle mesh, depth 20: 1.8 ms
@@ -731,7 +730,28 @@ int yahr_ctx_render(yahr_ctx *c, int32_t row0, int32_t row1, const yahr_render_o
     rp.lds_levels = c->ds.depth <= YD_LDS_DEPTH ? c->ds.depth : YD_LDS_LEVELS;
     const size_t extra = (size_t)(c->ds.depth - rp.lds_levels);
     if (extra > 0 && regroup) { set_error("the ray-regrouping diagnostics build keeps its level stack in LDS: recursion depth <= 3 only"); return YAHR_E_ARG; }
-    int chunk = n_blocks;
+    // the usual launch as a 3-D grid (frame, tile column, tile row): no integer division on the way to the pixel
+    rp.grid3d = 0;
+    if (rp.tile_mode == 0 && !regroup && !rp.xcd_swizzle && rp.row_order == nullptr && extra == 0 && rp.tiles_x > 0) {
+      rp.tile_rows = rp.n_tiles / rp.tiles_x;
+      if (rp.tile_rows <= 65535 && rp.tiles_x <= 65535) rp.grid3d = 1;
+    }
+    // A 1-D grid holds fewer than 2^32 work-items (the dispatch packet's grid size is 32 bits per dimension; the runtime
+    // does not refuse a larger one, it runs modulo 2^32): 2^26 - 8 wavefront-sized workgroups, a quarter of that in the
+    // regrouping build.  The 3-D grid is far from that in every dimension.  Every other launch holds as many WHOLE FRAMES
+    // of the batch as fit (one 8192 x 8192 x 64 spp frame is 2^26 workgroups and refused), the chunks of a deep scene
+    // are cut to it as well.
+    int max_blocks = ((1 << 26) - 8) / (regroup ? 4 : 1);
+    if (const char *e = std::getenv("YAHR_MAX_GRID_BLOCKS")) { const int v = std::atoi(e); if (v > 0) max_blocks = std::min(max_blocks, v); }   // tests
+    const int frames = rp.frames;
+    int fpl = frames;                                                        // frames per launch
+    if (!rp.grid3d) {
+      // (a deep scene's launches are cut into chunks below: whole frames only have to keep the block index in 31 bits)
+      const int cap = extra > 0 ? 0x7fffffff : max_blocks;
+      if (per_frame > cap) { set_error("image too large for one launch: more than 2^32 samples in a frame"); return YAHR_E_ARG; }
+      fpl = std::min(frames, cap / per_frame);
+    }
+    int chunk = (int)std::min<int64_t>((int64_t)per_frame * fpl, 0x7fffffff);          // workgroups of the largest launch
     if (extra > 0) {
       const size_t per_block = extra * 6 * 64 * sizeof(float);
       size_t fr = 0, tot = 0;
@@ -741,7 +761,8 @@ int yahr_ctx_render(yahr_ctx *c, int32_t row0, int32_t row1, const yahr_render_o
       budget = std::max(budget, c->spill_bytes);
       size_t fit = budget / per_block;
       if (fit == 0) { set_error("recursion depth too large: the level stack of one workgroup exceeds the device memory budget"); return YAHR_E_NOMEM; }
-      if (fit < (size_t)n_blocks) chunk = (int)fit;
+      if (fit < (size_t)chunk) chunk = (int)fit;
+      chunk = std::min(chunk, max_blocks);
       const size_t need = (size_t)chunk * per_block;
       if (need > c->spill_bytes) {
         if (c->d_spill) { HIP_TRY(hipFree(c->d_spill)); c->d_spill = nullptr; c->spill_bytes = 0; }
@@ -750,34 +771,19 @@ int yahr_ctx_render(yahr_ctx *c, int32_t row0, int32_t row1, const yahr_render_o
       }
       rp.lvl_spill = (float *)c->d_spill;
     }
-    // the usual launch as a 3-D grid (frame, tile column, tile row): no integer division on the way to the pixel
-    rp.grid3d = 0;
-    if (rp.tile_mode == 0 && !regroup && !rp.xcd_swizzle && rp.row_order == nullptr && extra == 0 && rp.tiles_x > 0) {
-      rp.tile_rows = rp.n_tiles / rp.tiles_x;
-      if (rp.tile_rows <= 65535 && rp.tiles_x <= 65535) rp.grid3d = 1;
-    }
-    // A 1-D grid holds fewer than 2^32 work-items (the dispatch packet's grid size is 32 bits per dimension): 2^26 - 8
-    // wavefront-sized workgroups (a quarter of that in the regrouping build).  The 3-D grid is far from that in every dimension; the chunked launches of a deep scene
-    // are cut to it; any other launch beyond it is a frame batch (one 8192 x 8192 x 64 spp frame is 2^26 workgroups
-    // and refused below), which is rendered as several launches of whole frames.
-    int max_blocks = ((1 << 26) - 8) / (regroup ? 4 : 1);
-    if (const char *e = std::getenv("YAHR_MAX_GRID_BLOCKS")) { const int v = std::atoi(e); if (v > 0) max_blocks = std::min(max_blocks, v); }   // tests
-    if (extra > 0) chunk = std::min(chunk, max_blocks);
-    if (!rp.grid3d && extra == 0 && n_blocks > max_blocks) {
-      const int frames = rp.frames, per_frame = n_blocks / frames;
-      if (per_frame > max_blocks) { set_error("image too large for one launch: more than 2^32 samples in a frame"); return YAHR_E_ARG; }
-      const int fpl = max_blocks / per_frame;                                // frames per launch
-      const DCold *cams = rp.cams;
-      for (int f0 = 0; f0 < frames; f0 += fpl) {
-        rp.frames = std::min(fpl, frames - f0);
-        rp.cams = cams ? cams + f0 : nullptr;
-        HIP_TRY(yahr_dev::launch_render(c->ds, rp, mode, regroup, per_frame * rp.frames, d_rgb + (size_t)f0 * rp.frame_stride, c->d_ctr,
-                                        o.collect_stats != 0, st));
-      }
-    } else {
-      for (int b0 = 0; b0 < n_blocks; b0 += chunk) {
-        rp.block0 = (unsigned)b0;
-        HIP_TRY(yahr_dev::launch_render(c->ds, rp, mode, regroup, std::min(chunk, n_blocks - b0), d_rgb, c->d_ctr, o.collect_stats != 0, st));
+    const DCold *cams = rp.cams;
+    for (int f0 = 0; f0 < frames; f0 += fpl) {
+      rp.frames = std::min(fpl, frames - f0);
+      rp.cams = cams ? cams + f0 : nullptr;
+      float *out = d_rgb + (size_t)f0 * rp.frame_stride;
+      const int n_launch = (int)std::min<int64_t>((int64_t)per_frame * rp.frames, 0x7fffffff);      // (3-D grid: not used)
+      if (extra == 0) {
+        HIP_TRY(yahr_dev::launch_render(c->ds, rp, mode, regroup, n_launch, out, c->d_ctr, o.collect_stats != 0, st));
+      } else {
+        for (int b0 = 0; b0 < n_launch; b0 += chunk) {
+          rp.block0 = (unsigned)b0;
+          HIP_TRY(yahr_dev::launch_render(c->ds, rp, mode, regroup, std::min(chunk, n_launch - b0), out, c->d_ctr, o.collect_stats != 0, st));
+        }
       }
     }
   }

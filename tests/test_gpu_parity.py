@@ -1252,6 +1252,19 @@ def test_device_bvh_build_is_the_host_tree(gpu, case, tris1m):
     assert _same_flat_scene(host.arrays(), dev.arrays()) is None
 
 
+def test_device_bvh_leaf_boxes_in_a_stride_loop(gpu, monkeypatch):
+    """trees of more than 4 M nodes (and every tree of more than 2^26: a grid cannot hold one wavefront per node there)
+    compute their leaf boxes in a grid-stride loop; here on small trees with the grid capped at 1 and 3 workgroups"""
+    for d in (scenes.random_tris(60_000, 16, 16, bvh_depth=18, seed=8), scenes.pseudo_bunny(32, 18)):
+        host = d.to_scene().set_builder(yahr_amd.BUILDER_HOST).build().arrays()
+        for cap in ("1", "3"):
+            monkeypatch.setenv("YAHR_BVH_LEAF_BLOCKS", cap)
+            dev = d.to_scene().set_builder(yahr_amd.BUILDER_DEVICE).build()
+            assert dev.builder_used()[0] == yahr_amd.BUILDER_DEVICE
+            assert _same_flat_scene(host, dev.arrays()) is None, cap
+        monkeypatch.delenv("YAHR_BVH_LEAF_BLOCKS")
+
+
 def test_device_bvh_build_declines_what_it_cannot_do(gpu):
     """SAH, non-finite boxes and tiny scenes stay with the host builder under AUTO; naming the device builder for them
     is an error, not a different tree"""

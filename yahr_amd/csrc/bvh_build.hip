@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -349,7 +350,9 @@ bool device_build_bvh(const float *boxes, int32_t n, int max_depth, std::vector<
     if (h[0] == n1) break;                                               // nothing was split on this level
   }
   const int total = lvl_start.back();
-  LAUNCH(k_leaf_boxes, dim3((unsigned)std::min<size_t>(((size_t)total + 3) / 4, (size_t)1 << 20)), dim3(256), 0, nullptr, total, d_nodes, it[cur], d_boxes);
+  size_t leaf_blocks = std::min<size_t>(((size_t)total + 3) / 4, (size_t)1 << 20);      // 4 wavefronts per workgroup, grid-stride beyond 4 M nodes
+  if (const char *e = std::getenv("YAHR_BVH_LEAF_BLOCKS")) { const long v = std::atol(e); if (v > 0) leaf_blocks = std::min(leaf_blocks, (size_t)v); }   // tests: the stride loop on small trees
+  LAUNCH(k_leaf_boxes, dim3((unsigned)leaf_blocks), dim3(256), 0, nullptr, total, d_nodes, it[cur], d_boxes);
   for (int l = (int)lvl_start.size() - 2; l >= 0; --l) {
     const int n0 = lvl_start[(size_t)l], n1 = lvl_start[(size_t)l + 1];
     if (n1 > n0) LAUNCH(k_bottom_up, dim3((n1 - n0 + 255) / 256), dim3(256), 0, nullptr, n0, n1, d_nodes);

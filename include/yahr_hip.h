@@ -40,8 +40,9 @@ extern "C" {
  * a larger yahr_stats written over its smaller one.
  *   1 -> 2: yahr_stats grew by wave_stage1_steps / wave_stage2_steps (16 bytes); yahr_render_opts.reserved[0] became
  *           stream_walker (same size); YAHR_TRAVERSE_STACK / _HYBRID_STACK / _ORDERED; yahr_multi_submit / _wait /
- *           _set_cameras, yahr_pinned_alloc / _free. */
-#define YAHR_ABI_VERSION 2
+ *           _set_cameras, yahr_pinned_alloc / _free.
+ *   2 -> 3: yahr_stats grew by tri_tests_culled / wave_cull_steps (16 bytes). */
+#define YAHR_ABI_VERSION 3
 
 enum {
   YAHR_OK = 0,
@@ -259,6 +260,9 @@ typedef struct yahr_stats {
   uint64_t max_wave_cycles, sum_wave_cycles;             /* shader clocks of the longest wavefront / of all (collect_stats only) */
   uint64_t wave_stage1_steps, wave_stage2_steps;         /* packet walker: primitive steps that ran the triangle's IEEE divide
                                                             (not rejected division-free by every live lane) / its second half */
+  uint64_t tri_tests_culled, wave_cull_steps;            /* packet walker, fat multiLeafs: triangle tests (part of tri_tests) whose
+                                                            outcome -- every lane far -- was proven for the whole packet at once
+                                                            instead of being executed / packet tests run (one per <= 64 triangles) */
 } yahr_stats;
 
 void yahr_default_opts(yahr_render_opts *o);

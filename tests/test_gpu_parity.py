@@ -148,7 +148,7 @@ def test_frame_batch_beyond_one_grid(gpu, monkeypatch):
     as several launches of whole frames, the chunked launches of a deep scene are cut to it.  Here with the limit lowered
     to 100 workgroups (YAHR_MAX_GRID_BLOCKS): the reference's tiling, the deep kernel and the diagnostics
     builds, nine cameras, bit for bit against the same batch in one launch -- and a frame that does not fit is refused."""
-    d = scenes.scene_fixed(64, 40)
+    d = scenes.scene_fixed(64, 40).with_(depth=2)         # (depth <= YD_LDS_DEPTH: the plain kernel; the deep one follows)
     scene = d.to_scene().build()
     ctx = yahr_amd.Context(scene, 0)
     cams = [dict(d.camera, pos=(-4 + 0.5 * i, 3, 2), look=(0.4, -0.3 - 0.02 * i, 1)) for i in range(9)]
@@ -821,6 +821,53 @@ def test_extreme_scene_renders_the_same_in_all_forms(gpu):
                 assert np.array_equal(bits(img), bits(ref)), (bvh_depth, spp, m)
                 for k in COUNT_KEYS:
                     assert st0[k] == st1[k], (k, bvh_depth, spp, m)
+
+
+def test_fat_leaf_culling_changes_nothing(gpu, monkeypatch):
+    """The packet walker settles most primitive steps of a fat multiLeaf for the whole packet at once (leaf_culled: the rays'
+    box in ray space, tri_stage0 in interval arithmetic, one triangle per lane).  A skipped step is one that would have
+    found every live lane `far`, so with the culling switched off (YAHR_NO_LEAF_CULL=1 when the context is created) the
+    image, every per-ray counter and even the number of primitive steps that went on to the IEEE divide are the same --
+    on meshes with fat leaves, shallow trees (leaves of hundreds), soups, spheres mixed in, coincident primitives with
+    exact ties, supersampling, and the adversarial operands of the extreme scene (subnormals, 1e38: those triangles
+    fail the magnitude limit per scene, so there the switch itself is what is tested)."""
+    rng = np.random.default_rng(21)
+    base = scenes.scene_fixed(128, 96)
+    dup = [scenes.plane_mesh(-2.2, "bottom"), scenes.plane_mesh(-2.2, "side"), scenes.plane_mesh(-2.2, "back")]
+    balls = [("sphere", (0, -1.2, 10), 1.0, "sphere"), ("sphere", (0, -1.2, 10), 1.0, "side")]
+    soup = []
+    for i in range(400):
+        c = rng.uniform(-3, 3, 3) + (0, 0, 9)
+        p = [tuple((c + rng.uniform(-0.3, 0.3, 3)).astype(np.float32).tolist()) for _ in range(3)]
+        n = tuple(rng.normal(size=3).astype(np.float32).tolist())
+        soup.append(("triangle", p[0], p[1], p[2], n, n, n, "sphere"))
+    cases = [(scenes.pseudo_bunny(320, 180), 1), (scenes.pseudo_bunny(160, 90, depth=4), 4),
+             (scenes.pseudo_bunny(96, 54, n_lon=48, n_lat=25, bvh_depth=3), 1), (scenes.pseudo_bunny(64, 36, n_lon=24, n_lat=13, bvh_depth=0), 16),
+             (scenes.random_tris(20000, 160, 90, bvh_depth=6), 1),
+             (base.with_(objects=dup + balls + soup + base.objects[:4], bvh_depth=2), 1),
+             (base.with_(objects=dup + balls + soup + base.objects[:4], bvh_depth=5, split="SurfaceAreaHeuristic"), 4)]
+    keys = COUNT_KEYS + ("wave_node_steps", "wave_stage1_steps", "wave_stage2_steps")
+    culled_somewhere = 0
+    for desc, spp in cases:
+        scene = desc.to_scene().build()
+        monkeypatch.setenv("YAHR_NO_LEAF_CULL", "1")
+        off = yahr_amd.Context(scene, 0)
+        monkeypatch.delenv("YAHR_NO_LEAF_CULL")
+        on = yahr_amd.Context(scene, 0)
+        for trav in (yahr_amd.TRAVERSE_PACKET, yahr_amd.TRAVERSE_HYBRID, yahr_amd.TRAVERSE_STREAM):
+            a = off.render(traverse=trav, spp=spp, seed=3, collect_stats=True).cpu().numpy(); sa = off.stats()
+            b = on.render(traverse=trav, spp=spp, seed=3, collect_stats=True).cpu().numpy(); sb = on.stats()
+            assert a.any() and np.array_equal(bits(a), bits(b)), (desc.bvh_depth, spp, trav)
+            for k in keys:
+                assert sa[k] == sb[k], (k, desc.bvh_depth, spp, trav)
+            assert sa["tri_tests_culled"] == 0 and sa["wave_cull_steps"] == 0
+            assert sb["tri_tests_culled"] <= sb["tri_tests"] and sb["wave_prim_steps"] <= sa["wave_prim_steps"]
+            if trav == yahr_amd.TRAVERSE_PACKET:
+                culled_somewhere += sb["tri_tests_culled"] > 0
+                # the fast build renders the same bits
+                assert np.array_equal(bits(on.render(traverse=trav, spp=spp, seed=3).cpu().numpy()), bits(a))
+        off.close(); on.close()
+    assert culled_somewhere >= 5
 
 
 @pytest.mark.parametrize("mode", [yahr_amd.TRAVERSE_AUTO, yahr_amd.TRAVERSE_STREAM])

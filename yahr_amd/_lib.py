@@ -69,7 +69,8 @@ class Stats(C.Structure):
                 ("shaded_hits", C.c_uint64), ("wave_node_steps", C.c_uint64), ("wave_prim_steps", C.c_uint64),
                 ("bad_material", C.c_uint64), ("kernel_ms", C.c_double), ("upload_ms", C.c_double),
                 ("max_wave_cycles", C.c_uint64), ("sum_wave_cycles", C.c_uint64),
-                ("wave_stage1_steps", C.c_uint64), ("wave_stage2_steps", C.c_uint64)]
+                ("wave_stage1_steps", C.c_uint64), ("wave_stage2_steps", C.c_uint64),
+                ("tri_tests_culled", C.c_uint64), ("wave_cull_steps", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

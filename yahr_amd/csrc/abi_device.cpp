@@ -395,6 +395,19 @@ static int ctx_create_impl(const yahr_scene *s, int device, yahr_ctx **out, size
     for (int k = 0; k < 3; ++k)
       if (!std::isfinite(s->nodes[i].lo[k]) || !std::isfinite(s->nodes[i].hi[k]) || !(s->nodes[i].lo[k] <= s->nodes[i].hi[k]))
         d.boxes_finite = 0;
+  // bit 1: every triangle record small enough for the packet-level tri_far proof (device_math.hpp: tri_far_packet;
+  // YAHR_NO_LEAF_CULL=1 switches the fat-leaf culling of the packet walker off: A/B measurements)
+  {
+    bool bounded = !(std::getenv("YAHR_NO_LEAF_CULL") && std::atoi(std::getenv("YAHR_NO_LEAF_CULL")) != 0);
+    for (int32_t i = 0; i < s->n_prims && bounded; ++i) {
+      const yahr_prim &p = s->prims[i];
+      if (p.kind != 0) continue;
+      for (int k = 0; k < 3; ++k)
+        if (!(std::fabs(p.p0[k]) <= 4294967296.0f) || !(std::fabs(p.e1[k]) <= 4294967296.0f) || !(std::fabs(p.e2[k]) <= 4294967296.0f))
+          bounded = false;
+    }
+    if (bounded) d.boxes_finite |= 2;
+  }
   // Is the wavefront form a candidate at all?  Then ask the scene how coherent its rays are: a probe render (four strips
   // of 8 rows of the scene camera's frame, 1 spp, packet walker, counted build) yields the lane utilisation of the packet
   // walker's node steps = box tests / (64 x wavefront node steps).  Triangle soups -- where compaction between bounces
@@ -727,7 +740,8 @@ int yahr_ctx_render(yahr_ctx *c, int32_t row0, int32_t row1, const yahr_render_o
     // recursionDepth is an unbounded Int upstream (Integrators.hs:18-20): the first YD_LDS_LEVELS levels of the (w_k, D_k)
     // stack live in LDS, the levels above them in a global array with one slice per workgroup of the launch.  A grid whose
     // slices would not fit the budget (an eighth of the free memory, at most 8 GiB) is cut into several launches.
-    rp.lds_levels = c->ds.depth <= YD_LDS_DEPTH ? c->ds.depth : YD_LDS_LEVELS;
+    // (the ray-regrouping diagnostics build has no spill path: it keeps up to three levels in LDS, as it always did)
+    rp.lds_levels = (c->ds.depth <= YD_LDS_DEPTH || (regroup && c->ds.depth <= 3)) ? c->ds.depth : YD_LDS_LEVELS;
     const size_t extra = (size_t)(c->ds.depth - rp.lds_levels);
     if (extra > 0 && regroup) { set_error("the ray-regrouping diagnostics build keeps its level stack in LDS: recursion depth <= 3 only"); return YAHR_E_ARG; }
     // the usual launch as a 3-D grid (frame, tile column, tile row): no integer division on the way to the pixel
@@ -857,6 +871,7 @@ void yahr_internal_counters_to_stats(const unsigned long long *h, yahr_stats *ou
   out->box_tests = h[CTR_BOX]; out->tri_tests = h[CTR_TRI]; out->sphere_tests = h[CTR_SPH];
   out->wave_node_steps = h[CTR_WAVE_NODES]; out->wave_prim_steps = h[CTR_WAVE_PRIMS];
   out->wave_stage1_steps = h[CTR_WAVE_STAGE1]; out->wave_stage2_steps = h[CTR_WAVE_STAGE2];
+  out->tri_tests_culled = h[CTR_TRI_CULLED]; out->wave_cull_steps = h[CTR_WAVE_CULLS];
   out->max_wave_cycles = h[CTR_MAX_WAVE_CYCLES]; out->sum_wave_cycles = h[CTR_SUM_WAVE_CYCLES];
 }
 extern "C" {

@@ -149,6 +149,60 @@ YD void tri_stage0(V3 p0, V3 e1, V3 e2, V3 o, V3 u, V3 &s, float &det, float &q)
   q = dot(s1, s);
 }
 YD bool tri_far(float q, float det) { return fabsf(q) > 1.5f * fabsf(det); }
+
+// tri_far for a whole PACKET of rays against one triangle, decided from the packet's bounding box in ray space:
+// every ray r of the packet has ol <= o_r <= oh and ul <= u_r <= uh component-wise (all finite).  The function
+// evaluates tri_stage0's expression tree -- the same binary32 operations in the same order -- in interval
+// arithmetic with ROUND-TO-NEAREST end points and returns true only if then |q_r| > 1.5 |det_r| holds for the
+// q_r, det_r that tri_stage0 COMPUTES for every such ray, i.e. every lane of the packet would report tri_far.
+// Why the enclosure holds for the computed (rounded) values, not just the real ones: rounding fl() is monotone
+// non-decreasing, and x - y, x + y (monotone in each argument) and x * y (bilinear: extrema over a box at its
+// corners) take their real-number extrema at corners of the operand box; so for x in [xl, xh], y in [yl, yh]
+//     fl(x - y) in [fl(xl - yh), fl(xh - yl)],    fl(x + y) in [fl(xl + yl), fl(xh + yh)],
+//     fl(x * y) in [min fl(corner products), max fl(corner products)]
+// and by induction over the expression tree every intermediate a lane computes lies in the interval computed
+// here.  Same argument as slab_hit_fast's, and like it only valid while no operation meets an infinity or a NaN
+// (inf - inf, 0 * inf; v_min / v_max would silently drop the NaN): the CALLER guarantees
+//     |o| <= 2^32, |u| <= 2^20 (checked on the packet's bounds), |p0|, |e1|, |e2| <= 2^32 (checked per scene on
+//     the host: DScene.boxes_finite bit 1)   =>   |s| <= 2^33, |s1| <= 2^53, |det|, |q| <= 2^88, 1.5 |det| <= 2^89,
+// far below binary32's 2^128, so nothing overflows and nothing is a NaN.  Subnormal results round (or flush) the
+// same way here and in tri_stage0 -- one kernel, one float mode -- and both are monotone.
+// Final step: fl(1.5 |det_r|) <= fl(1.5 max|det|) by monotonicity, min|q| <= |q_r|, so
+//     min|q| > fl(1.5 max|det|)   =>   tri_far(q_r, det_r) for every ray of the packet.
+// The packet walker then skips the primitive step for that triangle: by tri_far's own proof (above) no lane can
+// pass the b1 range test, so nothing a lane computes or stores changes -- only the skipped work.
+YD void ival_mul_point(float xl, float xh, float y, float &lo, float &hi) {
+  const float a = xl * y, b = xh * y;
+  lo = fminf(a, b); hi = fmaxf(a, b);
+}
+YD void ival_mul(float xl, float xh, float yl, float yh, float &lo, float &hi) {
+  const float a = xl * yl, b = xl * yh, c = xh * yl, d = xh * yh;
+  lo = fminf(fminf(a, b), fminf(c, d)); hi = fmaxf(fmaxf(a, b), fmaxf(c, d));
+}
+YD bool tri_far_packet(V3 p0, V3 e1, V3 e2, V3 ol, V3 oh, V3 ul, V3 uh) {
+  const V3 sl = ol - p0, sh = oh - p0;                                 // s = o - p0
+  // s1 = cross(u, e2) = (u.y e2.z - u.z e2.y, u.z e2.x - u.x e2.z, u.x e2.y - u.y e2.x)
+  float al, ah, bl, bh;
+  ival_mul_point(ul.y, uh.y, e2.z, al, ah); ival_mul_point(ul.z, uh.z, e2.y, bl, bh);
+  const float s1xl = al - bh, s1xh = ah - bl;
+  ival_mul_point(ul.z, uh.z, e2.x, al, ah); ival_mul_point(ul.x, uh.x, e2.z, bl, bh);
+  const float s1yl = al - bh, s1yh = ah - bl;
+  ival_mul_point(ul.x, uh.x, e2.y, al, ah); ival_mul_point(ul.y, uh.y, e2.x, bl, bh);
+  const float s1zl = al - bh, s1zh = ah - bl;
+  // det = (s1.x e1.x + s1.y e1.y) + s1.z e1.z
+  float xl, xh, yl, yh, zl, zh;
+  ival_mul_point(s1xl, s1xh, e1.x, xl, xh); ival_mul_point(s1yl, s1yh, e1.y, yl, yh); ival_mul_point(s1zl, s1zh, e1.z, zl, zh);
+  const float dl = (xl + yl) + zl, dh = (xh + yh) + zh;
+  // q = (s1.x s.x + s1.y s.y) + s1.z s.z
+  ival_mul(s1xl, s1xh, sl.x, sh.x, xl, xh); ival_mul(s1yl, s1yh, sl.y, sh.y, yl, yh); ival_mul(s1zl, s1zh, sl.z, sh.z, zl, zh);
+  const float ql = (xl + yl) + zl, qh = (xh + yh) + zh;
+  const float min_abs_q = fmaxf(fmaxf(ql, -qh), 0.0f);                 // 0 when the interval holds 0
+  const float max_abs_det = fmaxf(fabsf(dl), fabsf(dh));
+  return min_abs_q > 1.5f * max_abs_det;
+}
+// magnitude limits under which tri_far_packet cannot overflow (see above)
+#define YD_CULL_MAX_COORD 4294967296.0f      /* 2^32: ray origins, triangle vertices and edges */
+#define YD_CULL_MAX_DIR 1048576.0f           /* 2^20: ray directions */
 YD bool tri_stage1(float det, float q, float &inv, float &b1) {
   inv = 1.0f / det;
   b1 = q * inv;

@@ -71,8 +71,8 @@ struct Hit { int prim; float t, b1, b2; };   // prim = leaf-order record index, 
 // at wave-uniform program points with the popcount of a lane mask; the per-test counters are per lane
 // because they are bumped inside divergent control flow.
 struct Counters {
-  unsigned primary, reflection, shadow, shaded, wave_nodes, wave_prims, wave_stage1, wave_stage2;   // uniform
-  unsigned box, tri, sph;                                                 // per lane
+  unsigned primary, reflection, shadow, shaded, wave_nodes, wave_prims, wave_stage1, wave_stage2, wave_culls;   // uniform
+  unsigned box, tri, sph, tri_culled;                                     // per lane
 };
 YD unsigned lanes(bool p) { return (unsigned)__popcll(__ballot(p)); }
 
@@ -230,7 +230,7 @@ YD void traverse_lane(const DScene &sc, bool active, bool any_hit, V3 o, V3 u, f
   const V3 inv = v3(1.0f / u.x, 1.0f / u.y, 1.0f / u.z);
   hit.prim = -1; hit.t = 0.0f; hit.b1 = 0.0f; hit.b2 = 0.0f;
   // NaN-free slab form when the whole wave qualifies (see traverse_packet / device_math.hpp)
-  const bool fast = sc.boxes_finite != 0 && !wany(active & !slab_safe(o, inv));
+  const bool fast = (sc.boxes_finite & 1) != 0 && !wany(active & !slab_safe(o, inv));
   if (fast) lane_loop<STATS, true>(sc, active ? 0 : sc.n_nodes, any_hit, o, u, inv, tmax, hit, c);
   else lane_loop<STATS, false>(sc, active ? 0 : sc.n_nodes, any_hit, o, u, inv, tmax, hit, c);
 }
@@ -362,7 +362,7 @@ YD int stack_descend(const DScene &sc, const float4 *pairs, int *stk, int j, int
 
 // can this wavefront run the stack walker?  (pair records exist, NaN-free slab form legal for every active lane)
 YD bool stack_ok(const DScene &sc, const float4 *pairs, bool active, V3 o, V3 inv) {
-  return pairs != nullptr && sc.boxes_finite != 0 && !wany(active & !slab_safe(o, inv));
+  return pairs != nullptr && (sc.boxes_finite & 1) != 0 && !wany(active & !slab_safe(o, inv));
 }
 
 template <bool STATS, bool ORDERED>
@@ -409,6 +409,87 @@ YD int wave_min_i32(int v) {
   return __builtin_amdgcn_readlane(v, 63);
 }
 
+// Wave-wide minimum (maximum) of six floats at once: the DPP ladder of wave_min_i32 (row shifts 1, 2, 4, 8,
+// then the two row broadcasts; lane 63 ends up with the result), written as v_min_f32_dpp / v_max_f32_dpp so that the
+// cross-lane move rides on the arithmetic instruction (the compiler emits v_mov_b32_dpp + s_nop + a canonicalising
+// v_max + the v_min for every step of the builtin form: 24 instructions per reduction instead of 6).  A lane whose DPP
+// source does not exist (first lanes of a row for a shift, rows outside the row mask of a broadcast) keeps its value:
+// with bound_ctrl off such a lane's write is disabled.  The six ladders are interleaved, so every instruction reads
+// a register written six instructions earlier -- beyond the two wait states a DPP read of a fresh VALU result
+// needs (inline asm gets no automatic s_nop).  v_min / v_max ignore NaNs: callers pass NaN-free values (FAST
+// traversals only).  Needs the whole wave executing, like wave_min_i32.
+// (two ladders of six: with all twelve in one statement the packet kernel needs six more VGPRs at its peak)
+#define YD_LADDER6(op, ctl)                                                                      \
+  op " %0, %0, %0 " ctl "\n\t" op " %1, %1, %1 " ctl "\n\t" op " %2, %2, %2 " ctl "\n\t"        \
+  op " %3, %3, %3 " ctl "\n\t" op " %4, %4, %4 " ctl "\n\t" op " %5, %5, %5 " ctl "\n\t"
+#define YD_WAVE_REDUCE6(op)                                                                      \
+  asm(YD_LADDER6(op, "row_shr:1 row_mask:0xf bank_mask:0xf") YD_LADDER6(op, "row_shr:2 row_mask:0xf bank_mask:0xf")      \
+      YD_LADDER6(op, "row_shr:4 row_mask:0xf bank_mask:0xf") YD_LADDER6(op, "row_shr:8 row_mask:0xf bank_mask:0xf")      \
+      YD_LADDER6(op, "row_bcast:15 row_mask:0xa bank_mask:0xf") YD_LADDER6(op, "row_bcast:31 row_mask:0xc bank_mask:0xf") \
+      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5))
+YD void wave_min6(float &a0, float &a1, float &a2, float &a3, float &a4, float &a5) { YD_WAVE_REDUCE6("v_min_f32_dpp"); }
+YD void wave_max6(float &a0, float &a1, float &a2, float &a3, float &a4, float &a5) { YD_WAVE_REDUCE6("v_max_f32_dpp"); }
+#undef YD_WAVE_REDUCE6
+#undef YD_LADDER6
+YD float lane63(float x) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63)); }
+
+// ---- fat multiLeafs: most primitive steps proven away per PACKET ------------------------------------------------
+// A multiLeaf (Culling.hs:52-54) has no boxes inside: collideAll tests every primitive against every ray that enters
+// the joint box.  The reference's midpoint tree leaves fat ones wherever it runs out of depth -- the pseudo-bunny's
+// 35-triangle floor leaf (joint box = the whole floor slab) is entered by three rays in four and took 90 % of the
+// frame's triangle tests, each a full primitive step (28 VALU) that ends in "every live lane is tri_far".
+// Here the wavefront first settles that outcome for up to 64 triangles AT ONCE, one triangle per lane: the rays that
+// entered the leaf are bounded by a box in ray space (12 wave reductions), every lane runs tri_far_packet
+// (device_math.hpp: tri_stage0 in interval arithmetic, ~85 VALU) on its own triangle, and a ballot yields the
+// triangles that are NOT proven far for the whole packet.  Only those take the usual primitive step, in stored order.
+// A skipped step is one in which the existing code would have found every live lane far and done nothing (the
+// enclosure covers every ray that entered the leaf, live or not), so hits, t, tMax and every per-ray count are
+// untouched; counting builds add the skipped tests to tri_tests (the reference performs them) and to tri_culled.
+#ifndef YD_CULL_MIN
+#define YD_CULL_MIN 12                                 // primitives in a leaf from which the packet test pays
+#endif
+template <bool STATS, bool ANY>
+YD bool leaf_culled(const DScene &sc, int a, int b, bool h, V3 o, V3 u, float &tmax, Hit &hit, Counters &c) {
+  const float inf = __builtin_huge_valf();
+  // box of the rays that entered the leaf, in ray space (lanes outside contribute the identities)
+  float l0 = h ? o.x : inf, l1 = h ? o.y : inf, l2 = h ? o.z : inf, l3 = h ? u.x : inf, l4 = h ? u.y : inf, l5 = h ? u.z : inf;
+  wave_min6(l0, l1, l2, l3, l4, l5);
+  const V3 ol = v3(lane63(l0), lane63(l1), lane63(l2)), ul = v3(lane63(l3), lane63(l4), lane63(l5));
+  float g0 = h ? o.x : -inf, g1 = h ? o.y : -inf, g2 = h ? o.z : -inf, g3 = h ? u.x : -inf, g4 = h ? u.y : -inf, g5 = h ? u.z : -inf;
+  wave_max6(g0, g1, g2, g3, g4, g5);
+  const V3 oh = v3(lane63(g0), lane63(g1), lane63(g2)), uh = v3(lane63(g3), lane63(g4), lane63(g5));
+  // magnitudes under which the interval evaluation cannot overflow (wave-uniform values)
+  const float mo = fmaxf(fmaxf(fmaxf(fabsf(ol.x), fabsf(oh.x)), fmaxf(fabsf(ol.y), fabsf(oh.y))), fmaxf(fabsf(ol.z), fabsf(oh.z)));
+  const float mu = fmaxf(fmaxf(fmaxf(fabsf(ul.x), fabsf(uh.x)), fmaxf(fabsf(ul.y), fabsf(uh.y))), fmaxf(fabsf(ul.z), fabsf(uh.z)));
+  const bool bounded = (mo <= YD_CULL_MAX_COORD) & (mu <= YD_CULL_MAX_DIR);
+  const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  bool got = false;
+  for (int base = 0; base < a; base += 64) {                           // wave-uniform
+    const int n_here = a - base < 64 ? a - base : 64;
+    bool need = false;
+    if (lane < n_here) {
+      const PrimRec p = load_prim(sc, b + base + lane);                // per-lane record
+      const bool far_all = tri_far_packet(xyz(p.r0), xyz(p.r1), xyz(p.r2), ol, oh, ul, uh);
+      const bool is_tri = __float_as_int(p.r1.w) == 0;
+      need = !(is_tri & bounded & far_all);
+    }
+    unsigned long long m = __builtin_amdgcn_ballot_w64(need);
+    if (STATS) { c.wave_culls++; }
+    int prev = -1;
+    while (m != 0ULL) {                                                // wave-uniform
+      const int j = __builtin_ctzll(m);
+      m &= m - 1ULL;
+      const PrimRec p = load_prim(sc, b + base + j);                   // wave-uniform index: scalar load
+      const bool live = h & !(ANY & got);
+      if (STATS) { const unsigned skipped = live ? (unsigned)(j - prev - 1) : 0u; c.tri += skipped; c.tri_culled += skipped; c.wave_prims++; }
+      got |= test_prim_packet<STATS>(sc, b + base + j, p, live, o, u, tmax, hit, c);
+      prev = j;
+    }
+    if (STATS) { const unsigned skipped = (h & !(ANY & got)) ? (unsigned)(n_here - prev - 1) : 0u; c.tri += skipped; c.tri_culled += skipped; }
+  }
+  return got;
+}
+
 // The node index i is wave-uniform, so node and primitive records arrive through SCALAR loads into SGPRs.
 // The successor in array order (i+1: always the next node after a leaf, and the left child of a hit
 // interior node) and a leaf's first primitive are requested before the slab test of the current node, so
@@ -437,9 +518,9 @@ YD void packet_box(const NodeRec &nd, bool on, V3 o, V3 inv, float tmax, bool &h
 
 // One node step of the packet walker: `cur` is node i, the record of node i+1 is requested into `nxt` (padded
 // array: in bounds even for the last node).  Returns the index of the next node (>= n: traversal complete).
-template <bool STATS, bool FAST, bool ADAPT, bool ANY>
+template <bool STATS, bool FAST, bool ADAPT, bool ANY, bool CULL>
 YD int packet_step(const DScene &sc, const NodeRec &cur, NodeRec &nxt, int i, V3 o, V3 u, V3 inv, float &tmax, Hit &hit,
-                   int &wake, Counters &c, int &useful) {
+                   int &wake, Counters &c, int &useful, int cull_min) {
   constexpr bool any_hit = ANY;                        // first-hit (shadow) mode is a compile-time property here
   const int n = sc.n_nodes;
   const int a = __float_as_int(cur.lo.w), b = __float_as_int(cur.hi.w);
@@ -456,6 +537,10 @@ YD int packet_step(const DScene &sc, const NodeRec &cur, NodeRec &nxt, int i, V3
     packet_box<FAST>(cur, on, o, inv, tmax, h, anyh);
     if (anyh) {
       bool got = false;
+      // fat leaf (FAST loops only: every lane NaN-free): most of its primitive steps are settled per packet.
+      // cull_min = YD_CULL_MIN, or INT_MAX when the scene's triangles are not bounded (DScene.boxes_finite bit 1)
+      if (CULL && FAST && a >= cull_min) got = leaf_culled<STATS, any_hit>(sc, a, b, h, o, u, tmax, hit, c);
+      else {
 #ifdef YAHR_PRIO_FAT
       // a wavefront inside a fat multiLeaf is on a long serial chain: let it issue ahead of its SIMD's other waves
       if (a >= YAHR_PRIO_FAT) __builtin_amdgcn_s_setprio(3);
@@ -474,6 +559,7 @@ YD int packet_step(const DScene &sc, const NodeRec &cur, NodeRec &nxt, int i, V3
 #ifdef YAHR_PRIO_FAT
       if (a >= YAHR_PRIO_FAT) __builtin_amdgcn_s_setprio(0);
 #endif
+      }
       if (any_hit) {
         if (got) wake = YD_DONE;
         if (wany(got)) {
@@ -499,19 +585,20 @@ YD int packet_step(const DScene &sc, const NodeRec &cur, NodeRec &nxt, int i, V3
 // The loop body exists twice with the two node buffers swapped: a step to the next node in array order (every
 // leaf, every interior node some lane hit) finds its record already in the other buffer, without copying eight
 // SGPRs and without making the prefetch wait for the last use of the current node.
-template <bool STATS, bool FAST, bool ADAPT, bool ANY>
+template <bool STATS, bool FAST, bool ADAPT, bool ANY, bool CULL>
 YD int packet_loop(const DScene &sc, bool active, V3 o, V3 u, V3 inv, float &tmax, Hit &hit, int &wake, Counters &c) {
   const int n = sc.n_nodes;
   wake = active ? 0 : YD_DONE;
   int i = 0;                                           // wave-uniform: lives in an SGPR
   int window = YD_WINDOW, useful = 0;                  // wave-uniform
+  const int cull_min = (sc.boxes_finite & 2) ? YD_CULL_MIN : 0x7fffffff;   // wave-uniform (leaf_culled)
   NodeRec A = load_node(sc, 0), B;
   for (;;) {
     if (ADAPT) {
       if (window == 0) { if (useful < YD_WINDOW * YD_MIN_ACTIVE) return i; window = YD_WINDOW; useful = 0; }
       --window;
     }
-    int next = packet_step<STATS, FAST, ADAPT, ANY>(sc, A, B, i, o, u, inv, tmax, hit, wake, c, useful);
+    int next = packet_step<STATS, FAST, ADAPT, ANY, CULL>(sc, A, B, i, o, u, inv, tmax, hit, wake, c, useful, cull_min);
     if (next >= n) return n;
     if (next != i + 1) { A = load_node(sc, next); i = next; continue; }
     i = next;
@@ -519,7 +606,7 @@ YD int packet_loop(const DScene &sc, bool active, V3 o, V3 u, V3 inv, float &tma
       if (window == 0) { if (useful < YD_WINDOW * YD_MIN_ACTIVE) return i; window = YD_WINDOW; useful = 0; }
       --window;
     }
-    next = packet_step<STATS, FAST, ADAPT, ANY>(sc, B, A, i, o, u, inv, tmax, hit, wake, c, useful);
+    next = packet_step<STATS, FAST, ADAPT, ANY, CULL>(sc, B, A, i, o, u, inv, tmax, hit, wake, c, useful, cull_min);
     if (next >= n) return n;
     if (next != i + 1) A = load_node(sc, next);
     i = next;
@@ -529,7 +616,7 @@ YD int packet_loop(const DScene &sc, bool active, V3 o, V3 u, V3 inv, float &tma
 // ADAPT: packet while the rays stay coherent, then every lane on its own.  Both halves perform, per ray, the
 // reference's tests in the reference's order, so where the hand-off happens cannot change a result.
 // STK (ADAPT only): the lanes finish on the stack walker when the wavefront may run it (`stk` = the lane's LDS stack)
-template <bool STATS, bool ADAPT, bool STK = false>
+template <bool STATS, bool ADAPT, bool STK = false, bool CULL = true>
 YD void traverse_packet(const DScene &sc, bool active, bool any_hit, V3 o, V3 u, float tmax, Hit &hit, Counters &c,
                         int *stk = nullptr, const float4 *pairs = nullptr) {
   V3 inv = v3(1.0f / u.x, 1.0f / u.y, 1.0f / u.z);
@@ -537,17 +624,17 @@ YD void traverse_packet(const DScene &sc, bool active, bool any_hit, V3 o, V3 u,
   const int n = sc.n_nodes;
   if (n == 0 || !wany(active)) return;
   // every node box finite (host check) and no active lane able to form 0*inf or inf-inf in the slab test?
-  const bool fast = sc.boxes_finite != 0 && !wany(active & !slab_safe(o, inv));
+  const bool fast = (sc.boxes_finite & 1) != 0 && !wany(active & !slab_safe(o, inv));
   if (fast && !active) { o = vof(0.0f); inv = vof(1.0f); }     // inactive lanes: NaN-free too (packet_box)
   int wake, i;
   // four copies of the loop (fast/exact slab x closest/first hit), selected once per traversal: run-time flags
   // inside the loop cost scalar instructions on every step
   if (fast) {
-    if (any_hit) i = packet_loop<STATS, true, ADAPT, true>(sc, active, o, u, inv, tmax, hit, wake, c);
-    else i = packet_loop<STATS, true, ADAPT, false>(sc, active, o, u, inv, tmax, hit, wake, c);
+    if (any_hit) i = packet_loop<STATS, true, ADAPT, true, CULL>(sc, active, o, u, inv, tmax, hit, wake, c);
+    else i = packet_loop<STATS, true, ADAPT, false, CULL>(sc, active, o, u, inv, tmax, hit, wake, c);
   } else {
-    if (any_hit) i = packet_loop<STATS, false, ADAPT, true>(sc, active, o, u, inv, tmax, hit, wake, c);
-    else i = packet_loop<STATS, false, ADAPT, false>(sc, active, o, u, inv, tmax, hit, wake, c);
+    if (any_hit) i = packet_loop<STATS, false, ADAPT, true, CULL>(sc, active, o, u, inv, tmax, hit, wake, c);
+    else i = packet_loop<STATS, false, ADAPT, false, CULL>(sc, active, o, u, inv, tmax, hit, wake, c);
   }
   if (ADAPT && i < n) {
     // a lane that already has its first hit in any-hit mode is parked at YD_DONE >= n
@@ -566,16 +653,19 @@ YD void traverse_packet(const DScene &sc, bool active, bool any_hit, V3 o, V3 u,
 // `coherent` (wave-uniform): the rays are camera rays.  The adaptive walker then stays a packet to the end: neighbouring
 // camera rays share almost their whole path, and the hand-off to the lane walker only costs there (1 M triangles, 16 spp,
 // camera rays alone: adaptive 15.6 ms, packet 11.1 ms).  Which walker runs never changes a result.
-template <int MODE, bool STATS>
+// CULL: fat multiLeafs settled per packet (leaf_culled).  Off in the level launches of the wavefront form: those
+// walk the secondary rays of triangle SOUPS (AUTO takes that form for incoherent scenes only), whose packets are too
+// wide for the proof to succeed, and at 64 VGPRs the extra code costs the kernel a dozen spilled registers.
+template <int MODE, bool STATS, bool CULL = true>
 YD void traverse(const DScene &sc, bool active, bool any_hit, bool coherent, V3 o, V3 u, float tmax, Hit &hit, Counters &c,
                  int *stk = nullptr, const float4 *pairs = nullptr) {
   if (MODE == TRAV_LANE) traverse_lane<STATS>(sc, active, any_hit, o, u, tmax, hit, c);
   else if (MODE == TRAV_STACK) traverse_stack<STATS, false>(sc, pairs, stk, active, any_hit, o, u, tmax, hit, c);
   else if (MODE == TRAV_ORDERED) traverse_stack<STATS, true>(sc, pairs, stk, active, any_hit, o, u, tmax, hit, c);
-  else if (MODE == TRAV_PACKET) traverse_packet<STATS, false>(sc, active, any_hit, o, u, tmax, hit, c);
-  else if (coherent) traverse_packet<STATS, false>(sc, active, any_hit, o, u, tmax, hit, c);
-  else if (MODE == TRAV_ADAPT_STACK) traverse_packet<STATS, true, true>(sc, active, any_hit, o, u, tmax, hit, c, stk, pairs);
-  else traverse_packet<STATS, true>(sc, active, any_hit, o, u, tmax, hit, c);     // TRAV_ADAPTIVE
+  else if (MODE == TRAV_PACKET) traverse_packet<STATS, false, false, CULL>(sc, active, any_hit, o, u, tmax, hit, c);
+  else if (coherent) traverse_packet<STATS, false, false, CULL>(sc, active, any_hit, o, u, tmax, hit, c);
+  else if (MODE == TRAV_ADAPT_STACK) traverse_packet<STATS, true, true, CULL>(sc, active, any_hit, o, u, tmax, hit, c, stk, pairs);
+  else traverse_packet<STATS, true, false, CULL>(sc, active, any_hit, o, u, tmax, hit, c);     // TRAV_ADAPTIVE
 }
 
 // The three record arrays reach every kernel as `const T *__restrict__` KERNEL ARGUMENTS (and are bound into the
@@ -701,27 +791,79 @@ YD V3 material_at(const DScene &sc, int mat, V3 n, V3 dpdu, V3 wi, V3 wo) {
 // slice of a global array laid out the same way (recursionDepth is an unbounded Int upstream, Integrators.hs:18-20; LDS
 // is not).  Same values, same fold order: where a level is kept cannot change a result.  Without DEEP every level fits
 // LDS and no code for the spill exists.
+// Level slot k (six floats per thread: LDS, or -- DEEP, k >= lds_levels -- this workgroup's slice of the global spill).
+// `in_lds` is wave-uniform; written out per address space so that every access is a plain ds_ / global_ instruction.
+template <int B>
+YD void slot_put(float *lvl, float *spill, bool in_lds, int k, int lds_levels, int tid, int part, V3 v) {
+  if (in_lds) { float *q = lvl + ((size_t)k * 6 + 3 * part) * B + tid; q[0] = v.x; q[B] = v.y; q[2 * B] = v.z; }
+  else { float *q = spill + ((size_t)(k - lds_levels) * 6 + 3 * part) * B + tid; q[0] = v.x; q[B] = v.y; q[2 * B] = v.z; }
+}
+template <int B>
+YD V3 slot_get(const float *lvl, const float *spill, bool in_lds, int k, int lds_levels, int tid, int part) {
+  if (in_lds) {
+    const float *q = lvl + ((size_t)k * 6 + 3 * part) * B + tid;
+    asm("" : "+v"(q));                                  // (no forwarding of the stored registers: see radiance)
+    return v3(q[0], q[B], q[2 * B]);
+  }
+  const float *q = spill + ((size_t)(k - lds_levels) * 6 + 3 * part) * B + tid;
+  return v3(q[0], q[B], q[2 * B]);
+}
+
 template <int MODE, bool STATS, int WPB, bool DEEP = false>
-YD V3 radiance(const DScene &sc, bool valid, V3 ro, V3 rd, float *lds, float *xch, Counters &c, bool &bad_mat,
+YD V3 radiance(const DScene &sc, bool valid, V3 ro_in, V3 rd_in, float *lds, float *xch, Counters &c, bool &bad_mat,
                float *__restrict__ spill = nullptr, int lds_levels = 0) {
   constexpr int B = 64 * WPB;                                         // threads per workgroup
   const int tid = threadIdx.x;
   bool alive = valid;
   int levels = 0;
   const int L = sc.n_lights, per = L + 1, n_steps = sc.depth * per;
-  V3 x = vof(0.0f), n = vof(0.0f), dpdu = vof(0.0f), direct = vof(0.0f), cv = vof(0.0f);
+  V3 cv = vof(0.0f);
   int mat = -1;
+  // REGISTERS ACROSS A TRAVERSAL.  The traversal loops are where the time goes, and the packet kernel's budget is 72
+  // VGPRs (7 waves per SIMD); whatever the integrator keeps alive across a traversal comes out of that budget or goes to
+  // scratch memory.  So the state of the recursion lives in LDS between its uses, not in registers:
+  //   * the DifferentialGeometry of the level's hit (x, n, dpdu) in a parking area of eight floats per thread (the first
+  //     8 * B floats of `lds`; the (w_k, D_k) stack follows): written after the level's closest-hit traversal, read
+  //     before every shadow probe and after the last one;
+  //   * the level's ray and its running sum of direct light in the level's own slot, whose contents change over the
+  //     level:  [rd | ro] when the ray is cast (the slot of level k + 1 is where level k leaves the reflection ray)
+  //          -> [rd | direct] while the lights are probed -> [w_k | D_k] at the end, which is what the fold below reads.
+  // Every value is a block-local variable loaded where it is used; only cv (the light's contribution, formed before the
+  // probe), the material index and three flags cross a traversal in registers.  Addresses are laundered through an
+  // empty asm at every read so that the compiler cannot forward the stored registers to the loads (which would keep
+  // them alive after all).  Same values, same operations: where a value waits cannot change a result.
+  // LDS is handed out in granules of 1280 bytes on gfx950: 20 floats per thread are 5120 bytes per wavefront = 4 granules,
+  // room for 32 wavefronts per CU; the 21st float would cost a fifth granule and leave 25 where the packet kernel wants
+  // 28.  So x.x stays in a register (`x_x`) and eight floats are parked.
+  float *park = lds + tid;
+  float *lvl = lds + 8 * B;
+  float x_x = 0.0f;
+#define YD_PARK_STORE(x, n, dpdu) { x_x = x.x; park[0] = x.y; park[B] = x.z; park[2 * B] = n.x; park[3 * B] = n.y; \
+    park[4 * B] = n.z; park[5 * B] = dpdu.x; park[6 * B] = dpdu.y; park[7 * B] = dpdu.z; }
+#define YD_PARK_LOAD(x, n, dpdu) { const float *pk = park; asm("" : "+v"(pk)); x = v3(x_x, pk[0], pk[B]); \
+    n = v3(pk[2 * B], pk[3 * B], pk[4 * B]); dpdu = v3(pk[5 * B], pk[6 * B], pk[7 * B]); }
+  if (n_steps > 0) {
+    const bool in0 = !DEEP || 0 < lds_levels;
+    slot_put<B>(lvl, spill, in0, 0, lds_levels, tid, 0, rd_in);
+    slot_put<B>(lvl, spill, in0, 0, lds_levels, tid, 1, ro_in);
+  }
   for (int step = 0; step < n_steps; ++step) {
     const int k = step / per, phase = step - k * per;
-    V3 qo = ro, qd = rd; float qt = 1e6f; bool active;
+    const bool in_lds = !DEEP || k < lds_levels;                      // wave-uniform: where slot k lives
+    // (lanes that cast nothing get a harmless ray)
+    V3 qo = vof(0.0f), qd = v3(0.0f, 0.0f, 1.0f); float qt = 1e6f; bool active;
     if (phase == 0) {
       if (!block_any<WPB>(alive, xch)) break;
       if (STATS) { if (k == 0) c.primary += lanes(alive); else c.reflection += lanes(alive); }
       active = alive;
-      direct = vof(0.0f);
+      qd = slot_get<B>(lvl, spill, in_lds, k, lds_levels, tid, 0);
+      qo = slot_get<B>(lvl, spill, in_lds, k, lds_levels, tid, 1);
     } else {
       active = false;
       if (alive) {
+        V3 x, n, dpdu;
+        YD_PARK_LOAD(x, n, dpdu)
+        const V3 rd = slot_get<B>(lvl, spill, in_lds, k, lds_levels, tid, 0);
         const float4 *lights = cold_of(sc)->lights;
         const float4 l0 = lights[2 * (size_t)(phase - 1)], l1 = lights[2 * (size_t)(phase - 1) + 1];
         const V3 p2l = xyz(l0) - x;                                   // Lights.hs:17-19
@@ -744,29 +886,34 @@ YD V3 radiance(const DScene &sc, bool valid, V3 ro, V3 rd, float *lds, float *xc
       alive = alive && hit.prim >= 0;
       if (STATS) c.shaded += lanes(alive);
       if (alive) {
+        V3 x, n, dpdu;
+        const V3 rd = slot_get<B>(lvl, spill, in_lds, k, lds_levels, tid, 0), ro = slot_get<B>(lvl, spill, in_lds, k, lds_levels, tid, 1);
         mat = surface_of(sc, ro, rd, hit, x, n, dpdu);
-        // Map.! on a missing key (main.hs:55).  Only a lane flag here: a store inside this loop would make
+        YD_PARK_STORE(x, n, dpdu)
+        // Map.! on a missing key (main.hs:55).  Only a lane flag here: a GLOBAL store inside this loop would make
         // every later scene load "clobberable" and ban the scalar-load path of the packet walker.
         bad_mat = bad_mat | (mat < 0);
       }
+      slot_put<B>(lvl, spill, in_lds, k, lds_levels, tid, 1, vof(0.0f));          // direct = sum from 0
     } else if (alive) {
-      direct = direct + ((active && hit.prim < 0) ? cv : vof(0.0f));  // sum = foldl (+) 0, light order
+      const V3 direct = slot_get<B>(lvl, spill, in_lds, k, lds_levels, tid, 1);
+      slot_put<B>(lvl, spill, in_lds, k, lds_levels, tid, 1,
+                  direct + ((active && hit.prim < 0) ? cv : vof(0.0f)));          // sum = foldl (+) 0, light order
     }
     if (phase == L && alive) {
+      V3 x, n, dpdu;
+      YD_PARK_LOAD(x, n, dpdu)
+      const V3 rd = slot_get<B>(lvl, spill, in_lds, k, lds_levels, tid, 0);
       const V3 r = rd - scale(2.0f * dot(rd, n), n);                  // reflectionDir, Integrators.hs:46-47
       const V3 f_r = material_at(sc, mat, n, dpdu, r, vneg(rd));
       const V3 w = scale(dot(n, r), f_r);
-      if (!DEEP || k < lds_levels) {                                  // wave-uniform
-        float *slot = lds + (size_t)k * 6 * B + tid;
-        slot[0] = w.x; slot[B] = w.y; slot[2 * B] = w.z;
-        slot[3 * B] = direct.x; slot[4 * B] = direct.y; slot[5 * B] = direct.z;
-      } else {
-        float *slot = spill + (size_t)(k - lds_levels) * 6 * B + tid;
-        slot[0] = w.x; slot[B] = w.y; slot[2 * B] = w.z;
-        slot[3 * B] = direct.x; slot[4 * B] = direct.y; slot[5 * B] = direct.z;
-      }
+      slot_put<B>(lvl, spill, in_lds, k, lds_levels, tid, 0, w);      // slot k is now (w_k, D_k)
       levels = k + 1;
-      ro = x + scale(0.001f, r); rd = r;                              // Integrators.hs:41-43
+      if (k + 1 < sc.depth) {                                         // the reflection ray waits in slot k + 1 (Integrators.hs:41-43)
+        const bool in1 = !DEEP || k + 1 < lds_levels;
+        slot_put<B>(lvl, spill, in1, k + 1, lds_levels, tid, 0, r);
+        slot_put<B>(lvl, spill, in1, k + 1, lds_levels, tid, 1, x + scale(0.001f, r));
+      }
     }
   }
   V3 v = vof(0.0f);                                                   // vcast 0 _ = 0 / miss = 0
@@ -777,10 +924,12 @@ YD V3 radiance(const DScene &sc, bool valid, V3 ro, V3 rd, float *lds, float *xc
       v = (w * v) + d;
     }
   for (int k = (DEEP && levels > lds_levels ? lds_levels : levels) - 1; k >= 0; --k) {
-    const float *slot = lds + (size_t)k * 6 * B + tid;
+    const float *slot = lvl + (size_t)k * 6 * B + tid;
     V3 w = v3(slot[0], slot[B], slot[2 * B]), d = v3(slot[3 * B], slot[4 * B], slot[5 * B]);
     v = (w * v) + d;
   }
+#undef YD_PARK_STORE
+#undef YD_PARK_LOAD
   return v;
 }
 
@@ -797,9 +946,9 @@ YD unsigned wave_sum_u32(unsigned v) {
 }
 
 YD void flush_counters(const Counters &c, unsigned long long *ctr, int lane) {
-  const unsigned box = wave_sum_u32(c.box), tri = wave_sum_u32(c.tri), sph = wave_sum_u32(c.sph);
+  const unsigned box = wave_sum_u32(c.box), tri = wave_sum_u32(c.tri), sph = wave_sum_u32(c.sph), culled = wave_sum_u32(c.tri_culled);
   const unsigned vals[CTR_COUNT] = {c.primary, c.reflection, c.shadow, c.shaded, 0u,
-                                    box, tri, sph, c.wave_nodes, c.wave_prims, c.wave_stage1, c.wave_stage2};
+                                    box, tri, sph, c.wave_nodes, c.wave_prims, c.wave_stage1, c.wave_stage2, culled, c.wave_culls};
   if (lane == 0) {
 #pragma unroll
     for (int i = 0; i < CTR_COUNT; ++i)
@@ -905,7 +1054,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(MODE =
 void k_render(DScene sc_in, YD_SCENE_PARAMS, RParams rp, float *__restrict__ out, unsigned long long *__restrict__ ctr) {
   extern __shared__ float lds[];
   YD_SCENE_BIND
-  float *xch = lds + (size_t)(sc.depth > 0 ? sc.depth : 1) * 6 * 64 * WPB;   // exchange area (WPB > 1 only; never DEEP)
+  float *xch = lds + (size_t)(8 + (sc.depth > 0 ? sc.depth : 1) * 6) * 64 * WPB;   // exchange area (WPB > 1 only; never DEEP)
   // DEEP: this workgroup's slice of the level spill (levels beyond the LDS part; only ever touched by such levels)
   float *spill = DEEP ? rp.lvl_spill + (size_t)blockIdx.x * (size_t)(sc.depth - rp.lds_levels) * (6 * 64 * WPB) : nullptr;
   Counters c = {};
@@ -1159,7 +1308,7 @@ void k_stream_level(DScene sc_in, YD_SCENE_PARAMS_PAIRS, SParams sp, unsigned lo
     Hit hit;
     // the paths of a wavefront are neighbours in space (Morton order) and a shadow ray's direction follows from its
     // origin: coherent rays, so the adaptive walker stays a packet for them (1 M triangles: 38.3 -> 37.2 ms per frame)
-    traverse<MODE, STATS>(sc, active, true, true, qo, qdir, qt, hit, c, stk, a_pairs);
+    traverse<MODE, STATS, false>(sc, active, true, true, qo, qdir, qt, hit, c, stk, a_pairs);
     if (valid) direct = direct + ((active && hit.prim < 0) ? cv : vof(0.0f));   // sum = foldl (+) 0, light order
   }
   const V3 r = rd - scale(2.0f * dot(rd, n), n);                       // reflectionDir, Integrators.hs:46-47
@@ -1174,7 +1323,7 @@ void k_stream_level(DScene sc_in, YD_SCENE_PARAMS_PAIRS, SParams sp, unsigned lo
     const V3 ro2 = x + scale(0.001f, r);                               // Integrators.hs:41-43
     if (STATS) c.reflection += lanes(valid);
     Hit hit;
-    traverse<MODE, STATS>(sc, valid, false, false, ro2, r, 1e6f, hit, c, stk, a_pairs);
+    traverse<MODE, STATS, false>(sc, valid, false, false, ro2, r, 1e6f, hit, c, stk, a_pairs);
     const bool alive = valid && hit.prim >= 0;
     if (STATS) c.shaded += lanes(alive);
     V3 x2 = vof(0.0f), n2 = vof(0.0f), dpdu2 = vof(0.0f);
@@ -1289,7 +1438,8 @@ template <int MODE, int WPB>
 static hipError_t launch_render_mode(const DScene &sc, const RParams &rp, int n_blocks, float *out,
                                      unsigned long long *ctr, bool stats, hipStream_t st) {
   // per-level (w_k, D_k) stack of every thread, then (WPB > 1) the exchange area of traverse_block / block_any
-  const size_t lds_bytes = ((size_t)(rp.lds_levels > 0 ? rp.lds_levels : 1) * 6 * 64 * WPB +
+  // ... in front of it the parking area of radiance() (8 floats per thread)
+  const size_t lds_bytes = ((size_t)(8 + (rp.lds_levels > 0 ? rp.lds_levels : 1) * 6) * 64 * WPB +
                             (WPB > 1 ? 12 * 64 * WPB + 2 * WPB : 0)) * sizeof(float);
   if (WPB == 1 && rp.lds_levels < sc.depth) {            // deep scene: upper levels of the stack in rp.lvl_spill
     if (stats) hipLaunchKernelGGL((k_render<MODE, true, 1, true>), dim3(n_blocks), dim3(64), lds_bytes, st, sc, sc.nodes, sc.prims, sc.normals, rp, out, ctr);
@@ -1381,7 +1531,7 @@ hipError_t launch_trace(const DScene &sc, const DPairs &dp, int mode, int n, con
 hipError_t launch_radiance(const DScene &sc, int mode, int n, const float *rays, float *rgb,
                            unsigned long long *ctr, float *lvl_spill, int lds_levels, hipStream_t st) {
   const int nb = (n + 63) / 64;
-  const size_t lds_bytes = (size_t)(lds_levels > 0 ? lds_levels : 1) * 6 * 64 * sizeof(float);
+  const size_t lds_bytes = (size_t)(8 + (lds_levels > 0 ? lds_levels : 1) * 6) * 64 * sizeof(float);
   if (mode == TRAV_LANE) hipLaunchKernelGGL((k_radiance<TRAV_LANE>), dim3(nb), dim3(64), lds_bytes, st, sc, sc.nodes, sc.prims, sc.normals, n, rays, rgb, ctr, lvl_spill, lds_levels);
   else if (mode == TRAV_PACKET) hipLaunchKernelGGL((k_radiance<TRAV_PACKET>), dim3(nb), dim3(64), lds_bytes, st, sc, sc.nodes, sc.prims, sc.normals, n, rays, rgb, ctr, lvl_spill, lds_levels);
   else hipLaunchKernelGGL((k_radiance<TRAV_ADAPTIVE>), dim3(nb), dim3(64), lds_bytes, st, sc, sc.nodes, sc.prims, sc.normals, n, rays, rgb, ctr, lvl_spill, lds_levels);

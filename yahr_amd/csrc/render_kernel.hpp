@@ -24,7 +24,8 @@ struct DScene {
   const DCold *cold;
   int n_nodes, n_prims, n_mats, n_lights;
   int depth;
-  int boxes_finite;        // every node box has finite lo <= hi: enables the NaN-free slab form
+  int boxes_finite;        // bit 0: every node box has finite lo <= hi (enables the NaN-free slab form);
+                           // bit 1: every triangle record's p0, e1, e2 within +-2^32 (enables tri_far_packet, device_math.hpp)
 };
 
 // Child-pair records for the stack walkers (render_kernel.hip: stack_loop), handed to the kernels that may run them (kept
@@ -69,16 +70,17 @@ struct RParams {
   // (frames, tiles_x, tile_rows): blockIdx is (frame, tile column, tile row) and nothing has to be divided
   int grid3d, tile_rows;
 };
-// Scenes of recursion depth <= YD_LDS_DEPTH keep the whole radiance stack in LDS (1.5 KiB per level and wavefront);
-// deeper ones keep YD_LDS_LEVELS levels there (4.5 KiB: room for 32 wavefronts per CU) and the rest in the spill.
-// Depth 4 already pays for the spill: 6 KiB per wavefront left room for 26 wavefronts per CU where the packet kernel asks
-// for 28 (pseudo-bunny 3840x2160 x 64 spp, depth 4: 92.9 ms per frame with three levels in LDS + one spilled, 93.8 all-LDS).
+// Scenes of recursion depth <= YD_LDS_DEPTH keep the whole radiance stack in LDS (1.5 KiB per level and wavefront, behind
+// the 2 KiB parking area of radiance(): depth 2 = 5120 bytes = four of gfx950's 1280-byte LDS granules, room for 32
+// wavefronts per CU where the packet kernel asks for 28; a fifth granule would leave 25); deeper ones keep YD_LDS_LEVELS levels there and the rest in the spill (a level in global memory costs next
+// to nothing: pseudo-bunny 3840x2160 x 64 spp, depth 4, measured in round 3 with three levels in LDS + one spilled
+// 92.9 ms per frame, all four in LDS -- fewer wavefronts per CU -- 93.8).
 #ifdef YD_LDS_DEPTH_OVERRIDE
 #define YD_LDS_DEPTH YD_LDS_DEPTH_OVERRIDE
 #else
-#define YD_LDS_DEPTH 3
+#define YD_LDS_DEPTH 2
 #endif
-#define YD_LDS_LEVELS 3
+#define YD_LDS_LEVELS 2
 
 // Wavefront ("stream") form of the same path, for scenes whose secondary rays are incoherent: the radiance
 // recursion (Integrators.hs:22-43) is cut at its level boundaries into separate launches, and between two launches
@@ -117,7 +119,7 @@ enum { TRAV_LANE = 1, TRAV_PACKET = 2, TRAV_ADAPTIVE = 3, TRAV_STREAM = 4,
        TRAV_ORDERED = 7 };      // TRAV_STACK visiting the nearer child first (opt-in: YAHR_TRAVERSE_ORDERED)
 
 enum { CTR_PRIMARY = 0, CTR_REFLECTION, CTR_SHADOW, CTR_SHADED, CTR_BAD_MAT,
-       CTR_BOX, CTR_TRI, CTR_SPH, CTR_WAVE_NODES, CTR_WAVE_PRIMS, CTR_WAVE_STAGE1, CTR_WAVE_STAGE2, CTR_COUNT,
+       CTR_BOX, CTR_TRI, CTR_SPH, CTR_WAVE_NODES, CTR_WAVE_PRIMS, CTR_WAVE_STAGE1, CTR_WAVE_STAGE2, CTR_TRI_CULLED, CTR_WAVE_CULLS, CTR_COUNT,
        // appended after the summed counters: per-wave shader-clock statistics (collect_stats builds)
        CTR_MAX_WAVE_CYCLES = CTR_COUNT, CTR_SUM_WAVE_CYCLES, CTR_TOTAL };
 

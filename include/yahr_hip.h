@@ -41,7 +41,7 @@ extern "C" {
  *   1 -> 2: yahr_stats grew by wave_stage1_steps / wave_stage2_steps (16 bytes); yahr_render_opts.reserved[0] became
  *           stream_walker (same size); YAHR_TRAVERSE_STACK / _HYBRID_STACK / _ORDERED; yahr_multi_submit / _wait /
  *           _set_cameras, yahr_pinned_alloc / _free.
- *   2 -> 3: yahr_stats grew by tri_tests_culled / wave_cull_steps (16 bytes). */
+ *   2 -> 3: yahr_stats grew by tri_tests_culled / wave_cull_steps / tri_cull_violations (24 bytes). */
 #define YAHR_ABI_VERSION 3
 
 enum {
@@ -263,6 +263,8 @@ typedef struct yahr_stats {
   uint64_t tri_tests_culled, wave_cull_steps;            /* packet walker, fat multiLeafs: triangle tests (part of tri_tests) whose
                                                             outcome -- every lane far -- was proven for the whole packet at once
                                                             instead of being executed / packet tests run (one per <= 64 triangles) */
+  uint64_t tri_cull_violations;                          /* collect_stats builds execute every skipped test after all and count the
+                                                            lanes that contradict the proof: always 0 */
 } yahr_stats;
 
 void yahr_default_opts(yahr_render_opts *o);

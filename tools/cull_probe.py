@@ -49,8 +49,8 @@ sa = sb = None
 for tag, ctx in (("off", ctx_off), ("on", ctx_on)):
     run(ctx, 1, rounds=1, stats=True)
     s = ctx.stats()
-    print(tag, {k: s[k] for k in ("primary_rays", "reflection_rays", "shadow_rays", "shaded_hits", "box_tests", "tri_tests", "sphere_tests", "wave_node_steps", "wave_prim_steps", "wave_stage1_steps", "wave_stage2_steps", "tri_tests_culled", "wave_cull_steps")})
+    print(tag, {k: s[k] for k in ("primary_rays", "reflection_rays", "shadow_rays", "shaded_hits", "box_tests", "tri_tests", "sphere_tests", "wave_node_steps", "wave_prim_steps", "wave_stage1_steps", "wave_stage2_steps", "tri_tests_culled", "wave_cull_steps", "tri_cull_violations")})
     if tag == "off": sa = s
     else: sb = s
 keys = ("primary_rays", "reflection_rays", "shadow_rays", "shaded_hits", "box_tests", "tri_tests", "sphere_tests", "wave_node_steps")
-print("per-ray counters equal:", all(sa[k] == sb[k] for k in keys))
+print("per-ray counters equal:", all(sa[k] == sb[k] for k in keys), [(k, sa[k], sb[k]) for k in keys if sa[k] != sb[k]])

@@ -70,7 +70,7 @@ class Stats(C.Structure):
                 ("bad_material", C.c_uint64), ("kernel_ms", C.c_double), ("upload_ms", C.c_double),
                 ("max_wave_cycles", C.c_uint64), ("sum_wave_cycles", C.c_uint64),
                 ("wave_stage1_steps", C.c_uint64), ("wave_stage2_steps", C.c_uint64),
-                ("tri_tests_culled", C.c_uint64), ("wave_cull_steps", C.c_uint64)]
+                ("tri_tests_culled", C.c_uint64), ("wave_cull_steps", C.c_uint64), ("tri_cull_violations", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

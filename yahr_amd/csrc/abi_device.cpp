@@ -871,7 +871,7 @@ void yahr_internal_counters_to_stats(const unsigned long long *h, yahr_stats *ou
   out->box_tests = h[CTR_BOX]; out->tri_tests = h[CTR_TRI]; out->sphere_tests = h[CTR_SPH];
   out->wave_node_steps = h[CTR_WAVE_NODES]; out->wave_prim_steps = h[CTR_WAVE_PRIMS];
   out->wave_stage1_steps = h[CTR_WAVE_STAGE1]; out->wave_stage2_steps = h[CTR_WAVE_STAGE2];
-  out->tri_tests_culled = h[CTR_TRI_CULLED]; out->wave_cull_steps = h[CTR_WAVE_CULLS];
+  out->tri_tests_culled = h[CTR_TRI_CULLED]; out->wave_cull_steps = h[CTR_WAVE_CULLS]; out->tri_cull_violations = h[CTR_CULL_VIOL];
   out->max_wave_cycles = h[CTR_MAX_WAVE_CYCLES]; out->sum_wave_cycles = h[CTR_SUM_WAVE_CYCLES];
 }
 extern "C" {

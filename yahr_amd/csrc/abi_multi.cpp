@@ -436,7 +436,7 @@ int yahr_multi_wait(yahr_multi *m, yahr_stats *stats) {
     total.box_tests += q.box_tests; total.tri_tests += q.tri_tests; total.sphere_tests += q.sphere_tests;
     total.shaded_hits += q.shaded_hits; total.wave_node_steps += q.wave_node_steps; total.wave_prim_steps += q.wave_prim_steps;
     total.wave_stage1_steps += q.wave_stage1_steps; total.wave_stage2_steps += q.wave_stage2_steps;
-    total.tri_tests_culled += q.tri_tests_culled; total.wave_cull_steps += q.wave_cull_steps;
+    total.tri_tests_culled += q.tri_tests_culled; total.wave_cull_steps += q.wave_cull_steps; total.tri_cull_violations += q.tri_cull_violations;
     total.bad_material += q.bad_material;
     if (q.kernel_ms > total.kernel_ms) total.kernel_ms = q.kernel_ms;
     if (q.max_wave_cycles > total.max_wave_cycles) total.max_wave_cycles = q.max_wave_cycles;

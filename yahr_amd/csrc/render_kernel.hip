@@ -72,7 +72,7 @@ struct Hit { int prim; float t, b1, b2; };   // prim = leaf-order record index, 
 // because they are bumped inside divergent control flow.
 struct Counters {
   unsigned primary, reflection, shadow, shaded, wave_nodes, wave_prims, wave_stage1, wave_stage2, wave_culls;   // uniform
-  unsigned box, tri, sph, tri_culled;                                     // per lane
+  unsigned box, tri, sph, tri_culled, cull_viol;                          // per lane
 };
 YD unsigned lanes(bool p) { return (unsigned)__popcll(__ballot(p)); }
 
@@ -416,14 +416,16 @@ YD int wave_min_i32(int v) {
 // source does not exist (first lanes of a row for a shift, rows outside the row mask of a broadcast) keeps its value:
 // with bound_ctrl off such a lane's write is disabled.  The six ladders are interleaved, so every instruction reads
 // a register written six instructions earlier -- beyond the two wait states a DPP read of a fresh VALU result
-// needs (inline asm gets no automatic s_nop).  v_min / v_max ignore NaNs: callers pass NaN-free values (FAST
+// needs; inline asm gets no automatic s_nop, so the statement opens with its own: the compiler may well have written
+// the first operand in the instruction right before it.  v_min / v_max ignore NaNs: callers pass NaN-free values (FAST
 // traversals only).  Needs the whole wave executing, like wave_min_i32.
 // (two ladders of six: with all twelve in one statement the packet kernel needs six more VGPRs at its peak)
 #define YD_LADDER6(op, ctl)                                                                      \
   op " %0, %0, %0 " ctl "\n\t" op " %1, %1, %1 " ctl "\n\t" op " %2, %2, %2 " ctl "\n\t"        \
   op " %3, %3, %3 " ctl "\n\t" op " %4, %4, %4 " ctl "\n\t" op " %5, %5, %5 " ctl "\n\t"
 #define YD_WAVE_REDUCE6(op)                                                                      \
-  asm(YD_LADDER6(op, "row_shr:1 row_mask:0xf bank_mask:0xf") YD_LADDER6(op, "row_shr:2 row_mask:0xf bank_mask:0xf")      \
+  asm("s_nop 1\n\t"                                                                              \
+      YD_LADDER6(op, "row_shr:1 row_mask:0xf bank_mask:0xf") YD_LADDER6(op, "row_shr:2 row_mask:0xf bank_mask:0xf")      \
       YD_LADDER6(op, "row_shr:4 row_mask:0xf bank_mask:0xf") YD_LADDER6(op, "row_shr:8 row_mask:0xf bank_mask:0xf")      \
       YD_LADDER6(op, "row_bcast:15 row_mask:0xa bank_mask:0xf") YD_LADDER6(op, "row_bcast:31 row_mask:0xc bank_mask:0xf") \
       : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5))
@@ -474,7 +476,20 @@ YD bool leaf_culled(const DScene &sc, int a, int b, bool h, V3 o, V3 u, float &t
       need = !(is_tri & bounded & far_all);
     }
     unsigned long long m = __builtin_amdgcn_ballot_w64(need);
-    if (STATS) { c.wave_culls++; }
+    if (STATS) {
+      c.wave_culls++;
+      // counting builds CHECK the proof: every skipped test is evaluated per lane after all, and a lane that entered the
+      // leaf and is not `far` is a violation (yahr_stats.tri_cull_violations: zero, or the enclosure argument is broken)
+      unsigned long long skipped = ~m & (n_here < 64 ? (1ULL << n_here) - 1ULL : ~0ULL);
+      while (skipped != 0ULL) {
+        const int j = __builtin_ctzll(skipped);
+        skipped &= skipped - 1ULL;
+        const PrimRec p = load_prim(sc, b + base + j);
+        V3 s; float det, q;
+        tri_stage0(xyz(p.r0), xyz(p.r1), xyz(p.r2), o, u, s, det, q);
+        c.cull_viol += (h & !tri_far(q, det)) ? 1u : 0u;
+      }
+    }
     int prev = -1;
     while (m != 0ULL) {                                                // wave-uniform
       const int j = __builtin_ctzll(m);
@@ -856,8 +871,13 @@ YD V3 radiance(const DScene &sc, bool valid, V3 ro_in, V3 rd_in, float *lds, flo
       if (!block_any<WPB>(alive, xch)) break;
       if (STATS) { if (k == 0) c.primary += lanes(alive); else c.reflection += lanes(alive); }
       active = alive;
-      qd = slot_get<B>(lvl, spill, in_lds, k, lds_levels, tid, 0);
-      qo = slot_get<B>(lvl, spill, in_lds, k, lds_levels, tid, 1);
+      // (only the lanes that cast: a dead lane's slot holds whatever LDS held, and its direction still reaches the
+      // branch-free first stage of every primitive step -- a NaN there would send whole wavefronts into the IEEE divide
+      // of stage 1 for nothing)
+      if (alive) {
+        qd = slot_get<B>(lvl, spill, in_lds, k, lds_levels, tid, 0);
+        qo = slot_get<B>(lvl, spill, in_lds, k, lds_levels, tid, 1);
+      }
     } else {
       active = false;
       if (alive) {
@@ -946,9 +966,9 @@ YD unsigned wave_sum_u32(unsigned v) {
 }
 
 YD void flush_counters(const Counters &c, unsigned long long *ctr, int lane) {
-  const unsigned box = wave_sum_u32(c.box), tri = wave_sum_u32(c.tri), sph = wave_sum_u32(c.sph), culled = wave_sum_u32(c.tri_culled);
+  const unsigned box = wave_sum_u32(c.box), tri = wave_sum_u32(c.tri), sph = wave_sum_u32(c.sph), culled = wave_sum_u32(c.tri_culled), viol = wave_sum_u32(c.cull_viol);
   const unsigned vals[CTR_COUNT] = {c.primary, c.reflection, c.shadow, c.shaded, 0u,
-                                    box, tri, sph, c.wave_nodes, c.wave_prims, c.wave_stage1, c.wave_stage2, culled, c.wave_culls};
+                                    box, tri, sph, c.wave_nodes, c.wave_prims, c.wave_stage1, c.wave_stage2, culled, c.wave_culls, viol};
   if (lane == 0) {
 #pragma unroll
     for (int i = 0; i < CTR_COUNT; ++i)

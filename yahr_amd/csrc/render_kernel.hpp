@@ -119,7 +119,7 @@ enum { TRAV_LANE = 1, TRAV_PACKET = 2, TRAV_ADAPTIVE = 3, TRAV_STREAM = 4,
        TRAV_ORDERED = 7 };      // TRAV_STACK visiting the nearer child first (opt-in: YAHR_TRAVERSE_ORDERED)
 
 enum { CTR_PRIMARY = 0, CTR_REFLECTION, CTR_SHADOW, CTR_SHADED, CTR_BAD_MAT,
-       CTR_BOX, CTR_TRI, CTR_SPH, CTR_WAVE_NODES, CTR_WAVE_PRIMS, CTR_WAVE_STAGE1, CTR_WAVE_STAGE2, CTR_TRI_CULLED, CTR_WAVE_CULLS, CTR_COUNT,
+       CTR_BOX, CTR_TRI, CTR_SPH, CTR_WAVE_NODES, CTR_WAVE_PRIMS, CTR_WAVE_STAGE1, CTR_WAVE_STAGE2, CTR_TRI_CULLED, CTR_WAVE_CULLS, CTR_CULL_VIOL, CTR_COUNT,
        // appended after the summed counters: per-wave shader-clock statistics (collect_stats builds)
        CTR_MAX_WAVE_CYCLES = CTR_COUNT, CTR_SUM_WAVE_CYCLES, CTR_TOTAL };
 

@@ -67,6 +67,10 @@ WORKLOADS = {
                         "8 spheres + plane + 2 point lights, 1920x1080, 1 spp, Whitted depth 1, BVH 16 Midpoint",
                         (0.0, -1.2, 15.0)),
     "bunny_small": lambda: (scenes.pseudo_bunny(480, 270, depth=2), "pseudo-bunny 480x270 (smoke size)", (0.2, 0.9, 0.0)),
+    # BASELINE.json configs[0]: the bundled scene (repaired copy, scenes/scene_fixed.yahrr) at 256x256, 1 spp -- the
+    # reference's own CPU-runnable case; the CPU baseline of this line runs SINGLE-THREADED, as the config says
+    "scene_fixed": lambda: (scenes.scene_fixed(256, 256), "scene.yahrr (repaired: 7 spheres + 2-triangle plane, 1 point light), "
+                            "256x256, 1 spp, Whitted depth 3, BVH 16 Midpoint", (0.0, -1.2, 10.0)),
     # BASELINE.json configs[3] and [4]; spp > 1 and "stratified" are build extensions (sampler)
     "bunny4k": lambda: (scenes.pseudo_bunny(3840, 2160, depth=4),
                         "pseudo-bunny 3840x2160, 64 spp stratified, Whitted depth 4 (primary + 3 reflection segments)",
@@ -310,7 +314,8 @@ def main():
 
     def ray_counts(st):
         t = torch.tensor([st["primary_rays"], st["reflection_rays"], st["shadow_rays"], st["box_tests"],
-                          st["wave_node_steps"], st["tri_tests"] + st["sphere_tests"], st["wave_prim_steps"]],
+                          st["wave_node_steps"], st["tri_tests"] + st["sphere_tests"] - st["tri_tests_culled"], st["wave_prim_steps"],
+                          st["tri_tests_culled"], st["wave_cull_steps"], st["tri_cull_violations"]],
                          dtype=torch.int64, device=dev)
         if world > 1:
             dist.all_reduce(t)
@@ -343,6 +348,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    pipe.reset_timing()
+    pipe.timing = True                      # (events only: per launch one behind the render, one behind gather + assembly)
     for _ in range(R):
         block(True)
     img = pipe.drain()                      # every launch rendered, gathered and assembled before the clock stops
@@ -359,9 +366,15 @@ def main():
     checksum = float(img[0].double().sum().item()) if rank == 0 else 0.0
     kern_ms = [a.elapsed_time(b) for a, b in timed_ev]
     kernel_ms_avg = sum(kern_ms) / len(kern_ms) if kern_ms else float("nan")
+    pipe.timing = False
+    # the exchange step of every timed launch on this rank: its duration and the part of it the next render did not hide
+    gt = pipe.gather_times()
+    gather_ms_avg = sum(g for g, _ in gt) / len(gt) if gt else 0.0
+    gather_exposed_ms_avg = sum(e for _, e in gt) / len(gt) if gt else 0.0
     # what every rank saw: its device, the world size of its process group, its own launch time
     mine = torch.tensor([float(local_rank), float(dist.get_world_size() if world > 1 else 1), kernel_ms_avg,
-                         float(yahr_amd.shard_rows(h, world, rank, args.strip_rows))], dtype=torch.float64, device=dev)
+                         float(yahr_amd.shard_rows(h, world, rank, args.strip_rows)), gather_ms_avg, gather_exposed_ms_avg],
+                        dtype=torch.float64, device=dev)
     table = torch.zeros((world, mine.numel()), dtype=torch.float64, device=dev)
     table[rank] = mine
     if world > 1:
@@ -397,15 +410,20 @@ def main():
                 "frames_per_launch": F, "launches_timed": len(kern_ms),
                 "kernel_source_sha256": src_hash[:16], "profile_matches_source": matches,
                 "per_rank": [{"rank": i, "device": int(r[0]), "world_size_seen": int(r[1]), "rows": int(r[3]),
-                              "kernel_ms_avg": round(r[2], 4)} for i, r in enumerate(per_rank)]}
+                              "kernel_ms_avg": round(r[2], 4), "gather_ms_avg": round(r[4], 4),
+                              "gather_exposed_ms_avg": round(r[5], 4)} for i, r in enumerate(per_rank)]}
         node_steps, node_lanes, prim_lanes, prim_steps = steps_full[1], steps_full[0], steps_full[2], steps_full[3]
         # lanes that were logically at work per wavefront step (counted launch of the same batch): an issue fraction
         # says the VALU is busy, this says how much of what it issues is useful
         roof["lane_utilisation"] = {
             "node_steps": round(node_lanes / (64.0 * node_steps), 4) if node_steps else None,
             "primitive_steps": round(prim_lanes / (64.0 * prim_steps), 4) if prim_steps else None,
-            "source": "box tests / (64 x wavefront node steps), primitive tests / (64 x wavefront primitive steps) of the "
-                      "counted launch; wavefront steps are counted by the packet walker only"}
+            "source": "box tests / (64 x wavefront node steps), EXECUTED primitive tests / (64 x wavefront primitive steps) of "
+                      "the counted launch; wavefront steps are counted by the packet walker only"}
+        # fat multiLeafs: triangle tests whose outcome was proven per packet instead of being executed (part of tri_tests)
+        roof["leaf_culling"] = {"tri_tests_settled_per_packet": steps_full[4], "packet_tests": steps_full[5],
+                                "share_of_primitive_tests": round(steps_full[4] / max(1, steps_full[4] + steps_full[2]), 4),
+                                "violations_found_by_the_counting_build": steps_full[6]}
         if prof is not None and kern_ms and matches:
             # what the counters say bounds the kernel: vector-instruction issue.  Instruction
             # counts are deterministic per frame, so the profile's per-frame figures (mean over the cameras of the
@@ -437,6 +455,12 @@ def main():
         # so this is not HBM traffic and is not a fraction of anything
         roof["algorithmic_bytes_per_launch"] = alg
         roof["algorithmic_gbs"] = round(alg / (kernel_ms_avg * 1e-3) / 1e9, 1) if kern_ms else None
+        # ... and as SURVEY 8(d) literally defines the roofline: algorithmic bytes / kernel time / (8 TB/s x GPUs).  A value
+        # above 1 does NOT mean skipped work (the counters equal the oracle's): the model charges every LANE 32 B per box
+        # test, the packet walker fetches a record once per WAVEFRONT by scalar load, so the model does not bound it
+        roof["survey_8d_frac"] = round(alg / (kernel_ms_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kern_ms else None
+        roof["survey_8d_note"] = ("algorithmic bytes of rank 0's launch / its kernel time / 8 TB/s; > 1 is possible because the "
+                                  "per-lane byte model does not bound a per-wavefront (scalar) fetch")
         out = {
             "metric": "Mrays/s (primary + reflection + shadow rays cast), bunny scene 1920x1080" if args.workload == "bunny"
                       else f"Mrays/s, {args.workload}",
@@ -447,6 +471,10 @@ def main():
             "timed_region_s": round(elapsed, 4),
             "ms_per_step": round(elapsed / n_steps * 1e3, 4),
             "single_frame_ms": round(single_ms, 4),
+            # the exchange step per launch on rank 0 (gather over RCCL + assembly on a side stream): from the end of the
+            # launch's render to the assembled images, and the part of that which the NEXT launch's render did not hide
+            # (one rank: there is no exchange step, both are 0; every rank's own figures are in roofline.per_rank)
+            "gather_ms_avg": round(per_rank[0][4], 4), "gather_exposed_ms_avg": round(per_rank[0][5], 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32",
             "data": ("synthetic (procedural pseudo-bunny: no bunny mesh ships with the reference)"
@@ -464,12 +492,14 @@ def main():
             "image_checksum": checksum,
         }
         if world == 1 and not args.no_cpu_baseline:
-            cores = min(16, os.cpu_count() or 1)
+            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)   # every core this process may use
             def gpu_rows(r0, r1):               # the HIP path's rows of the scene camera's frame, same sampler and seed
                 t = torch.zeros((r1 - r0, w, 3), dtype=torch.float32, device=dev)
                 ctx.render_into(t.data_ptr(), r0, r1, yahr_amd.make_opts(traverse=trav, spp=spp, seed=0), stream.cuda_stream)
                 torch.cuda.synchronize()
                 return t.cpu().numpy()
+            if args.workload == "scene_fixed":
+                cores = 1                       # configs[0]: "Haskell CPU path single-threaded"
             cb, ost, par = cpu_baseline(desc, cores, spp, gpu_rows=gpu_rows)
             out["cpu_baseline"] = cb
             out["parity"] = par

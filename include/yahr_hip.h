@@ -157,7 +157,11 @@ int yahr_scene_end_subsampled(yahr_host_scene *s);
 
 /* Who builds the BVH.  The device builder (midpoint split, finite boxes) works level by level on the GPU and yields the
  * IDENTICAL node array and leaf order as the host builder; AUTO uses it for scenes of 32768 primitives and more when a
- * device is visible and falls back to the host silently; DEVICE fails the build if it cannot be used. */
+ * device is visible and falls back to the host silently; DEVICE fails the build if it cannot be used.
+ * SIDE EFFECT: with AUTO (the default) or DEVICE, yahr_scene_build / yahr_scene_flat of such a scene INITIALISE HIP and
+ * launch kernels on the device that is CURRENT in the calling thread -- not necessarily the one later given to
+ * yahr_ctx_create.  A host that builds scenes in a launcher process before it forks or spawns its GPU workers must keep
+ * the build on the CPU: yahr_scene_set_builder(s, YAHR_BUILDER_HOST), or YAHR_BVH_BUILDER=host in the environment. */
 enum { YAHR_BUILDER_AUTO = 0, YAHR_BUILDER_HOST = 1, YAHR_BUILDER_DEVICE = 2 };
 int yahr_scene_set_builder(yahr_host_scene *s, int32_t builder);
 /* after yahr_scene_build: YAHR_BUILDER_HOST or YAHR_BUILDER_DEVICE; *device_ms = device time of the build (0 on the host) */

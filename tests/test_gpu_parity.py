@@ -1140,6 +1140,16 @@ def test_multi_object_n_device_plan_rehearsed_on_one_gpu(gpu, n, strip):
     ctx.set_cameras(cams)
     assert np.array_equal(bits(x), bits(ctx.render(frames=3).cpu().numpy()))
     assert np.array_equal(bits(y), bits(ctx.render(frames=3, spp=4, seed=5).cpu().numpy()))
+    # page-locked buffers are recycled: a submit / wait loop that releases what it has consumed allocates nothing more
+    want = bits(x).copy()
+    m.release(x); m.release(y)
+    n_alloc = len(m._pinned)
+    for _ in range(6):
+        z = m.submit(frames=3)
+        got, _ = m.wait()
+        assert got is z and np.array_equal(bits(got), want)
+        m.release(got)
+    assert len(m._pinned) == n_alloc == 2
     ctx.close()
     m.close()
 

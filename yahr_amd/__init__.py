@@ -320,6 +320,7 @@ class MultiContext:
         h = C.c_void_p()
         devs = None if devices is None else (C.c_int * len(devices))(*devices)
         self._pinned, self._inflight = [], []
+        self._pool, self._owner = {}, {}          # page-locked buffers: free ones per shape; address -> (pointer, shape) of those handed out
         check(lib.yahr_multi_create(scene.flat, n_devices, devs, gather, strip_rows, C.byref(h)))
         self._h = h
 
@@ -335,12 +336,28 @@ class MultiContext:
         shape = (self.scene.height, self.scene.width, 3) if frames <= 1 else (frames, self.scene.height, self.scene.width, 3)
         if not pinned:
             return np.zeros(shape, dtype=np.float32)
+        # page-locked buffers are RECYCLED: a pool per shape, fed by release(); a submit / wait loop that releases what it
+        # has consumed holds two buffers (the two submissions in flight), whatever its length
         n = int(np.prod(shape))
-        p = lib.yahr_pinned_alloc(4 * n)
-        if not p:
-            raise MemoryError("yahr_pinned_alloc")
-        self._pinned.append(p)
-        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(n,)).reshape(shape)
+        pool = self._pool.setdefault(shape, [])
+        if pool:
+            p = pool.pop()
+        else:
+            p = lib.yahr_pinned_alloc(4 * n)
+            if not p:
+                raise MemoryError("yahr_pinned_alloc")
+            self._pinned.append(p)
+        arr = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(n,)).reshape(shape)
+        self._owner[arr.ctypes.data] = (p, shape)
+        return arr
+
+    def release(self, arr):
+        """hand a page-locked array returned by submit() / wait() back for reuse (no-op for pageable arrays).  The
+        array must not be touched afterwards: the next submit() of that shape overwrites it."""
+        key = arr.ctypes.data if isinstance(arr, np.ndarray) else None
+        ent = self._owner.pop(key, None)
+        if ent is not None:
+            self._pool.setdefault(ent[1], []).append(ent[0])
 
     def render(self, **kw):
         """one frame (or a batch: frames=F) -> (numpy [h, w, 3] or [F, h, w, 3], stats dict)"""
@@ -356,15 +373,21 @@ class MultiContext:
         check(lib.yahr_multi_set_cameras(self._h, cams.shape[0], _fptr(cams) if cams.shape[0] else None))
 
     def submit(self, pinned=True, **kw):
-        """asynchronous: queue a frame batch; returns the (page-locked) host array the matching wait() fills"""
+        """asynchronous: queue a frame batch; returns the (page-locked) host array the matching wait() fills.  Page-locked
+        arrays come from a pool: release() the ones you are done with and a submit / wait loop allocates two in all."""
         o = make_opts(**kw)
         out = self._out(o.frames, pinned)
-        check(lib.yahr_multi_submit(self._h, C.byref(o), _fptr(out)))
+        try:
+            check(lib.yahr_multi_submit(self._h, C.byref(o), _fptr(out)))
+        except Exception:
+            self.release(out)                  # a failed submission keeps no buffer
+            raise
         self._inflight.append(out)
         return out
 
     def wait(self):
-        """complete the oldest submission -> (its host array, its stats)"""
+        """complete the oldest submission -> (its host array, its stats).  A page-locked array is a VIEW of memory this
+        object owns: copy it (or finish with it) before close(), and give it back with release() in a long loop."""
         st = Stats()
         check(lib.yahr_multi_wait(self._h, C.byref(st)))
         return self._inflight.pop(0), st.as_dict()
@@ -375,7 +398,7 @@ class MultiContext:
             lib.yahr_multi_destroy(h)
             for p in getattr(self, "_pinned", []):
                 lib.yahr_pinned_free(p)
-            self._pinned = []
+            self._pinned, self._pool, self._owner = [], {}, {}
 
     def __del__(self):
         self.close()

@@ -794,9 +794,9 @@ int yahr_ctx_render(yahr_ctx *c, int32_t row0, int32_t row1, const yahr_render_o
       if (extra == 0) {
         HIP_TRY(yahr_dev::launch_render(c->ds, rp, mode, regroup, n_launch, out, c->d_ctr, o.collect_stats != 0, st));
       } else {
-        for (int b0 = 0; b0 < n_launch; b0 += chunk) {
+        for (int64_t b0 = 0; b0 < n_launch; b0 += chunk) {                // (64-bit: n_launch may be close to 2^31)
           rp.block0 = (unsigned)b0;
-          HIP_TRY(yahr_dev::launch_render(c->ds, rp, mode, regroup, std::min(chunk, n_launch - b0), out, c->d_ctr, o.collect_stats != 0, st));
+          HIP_TRY(yahr_dev::launch_render(c->ds, rp, mode, regroup, (int)std::min<int64_t>(chunk, n_launch - b0), out, c->d_ctr, o.collect_stats != 0, st));
         }
       }
     }

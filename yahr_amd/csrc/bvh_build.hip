@@ -223,8 +223,11 @@ __global__ void k_leaf_boxes(int n_nodes, BNode *nodes, const float4 *__restrict
   // folds is the fold of the concatenation: min keeps its left operand on a tie, max its right one).  A grid-stride loop:
   // one wavefront per node in one launch would be 64 work-items per node, and a grid holds fewer than 2^32 of them (the
   // trees of 34 M primitives and more have over 2^26 nodes).
-  const int lane = threadIdx.x & 63, stride = (int)(gridDim.x * (blockDim.x >> 6));
-  for (int j = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); j < n_nodes; j += stride) {      // (j is wave-uniform)
+  // (64-bit counter: up to 2^31 nodes plus one stride of up to 2^22 does not fit an int)
+  const int lane = threadIdx.x & 63;
+  const long long stride = (long long)gridDim.x * (blockDim.x >> 6);
+  for (long long jj = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); jj < (long long)n_nodes; jj += stride) {      // (wave-uniform)
+    const int j = (int)jj;
     BNode &nd = nodes[j];
     if (nd.left >= 0) continue;
     const float inf = __builtin_huge_valf();

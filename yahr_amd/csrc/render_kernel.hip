@@ -85,21 +85,29 @@ struct PrimRec { float4 r0, r1, r2; };        // yahr_prim as three 16-byte word
 #ifndef YAHR_OFF32
 #define YAHR_OFF32 1
 #endif
-YD NodeRec load_node(const DScene &sc, int i) {
-#if YAHR_OFF32
-  const float4 *q = (const float4 *)((const char *)sc.nodes + ((unsigned)i << 5));
+// The record arrays are read through CONSTANT-address-space pointers (addrspace 4: memory that nothing writes while the
+// kernel runs -- true of the scene): a load with a wave-uniform address is then a scalar load (s_load_dwordx8 / x4 into
+// SGPRs) BY CONSTRUCTION.  As plain global loads they are scalar only while the compiler can prove that nothing ahead
+// of them may have written memory -- a store, an atomic, a barrier or an inline-asm statement in front silently turned
+// the packet walker's record fetches into per-lane gathers (2x slower, still correct; `const __restrict__` kernel
+// arguments cured the first three, the octant run's assembly needed this).  With a per-lane address (lane walker) the
+// same code is an ordinary vector load.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) f4v *cf4p;
+YD float4 ld4(const float4 *base, unsigned byte_off, int k) {
+  const f4v v = ((cf4p)(unsigned long long)((const char *)base + byte_off))[k];
+  return make_float4(v.x, v.y, v.z, v.w);
+}
 #else
-  const float4 *q = sc.nodes + 2 * (size_t)i;
+YD float4 ld4(const float4 *base, unsigned byte_off, int k) { return ((const float4 *)((const char *)base + byte_off))[k]; }   // (host pass: never runs)
 #endif
-  NodeRec n; n.lo = q[0]; n.hi = q[1]; return n;
+YD NodeRec load_node(const DScene &sc, int i) {
+  NodeRec n; n.lo = ld4(sc.nodes, (unsigned)i << 5, 0); n.hi = ld4(sc.nodes, (unsigned)i << 5, 1); return n;
 }
 YD PrimRec load_prim(const DScene &sc, int i) {
-#if YAHR_OFF32
-  const float4 *pr = (const float4 *)((const char *)sc.prims + (unsigned)i * 48u);
-#else
-  const float4 *pr = sc.prims + 3 * (size_t)i;
-#endif
-  PrimRec p; p.r0 = pr[0]; p.r1 = pr[1]; p.r2 = pr[2]; return p;
+  PrimRec p; p.r0 = ld4(sc.prims, (unsigned)i * 48u, 0); p.r1 = ld4(sc.prims, (unsigned)i * 48u, 1); p.r2 = ld4(sc.prims, (unsigned)i * 48u, 2);
+  return p;
 }
 // wave-uniform "any lane": compare the ballot itself (HIP's __any() goes through an integer VGPR)
 #if YAHR_OFF32
@@ -531,6 +539,38 @@ YD void packet_box(const NodeRec &nd, bool on, V3 o, V3 inv, float tmax, bool &h
   }
 }
 
+// The primitives of a leaf some lane entered (h = the lanes that did): collideAll over the multiLeaf in stored order
+// (Culling.hs:52-54, Rays.hs:39-46).  p0 = the record of the leaf's first primitive, requested by the caller before
+// its slab test.  Returns got = the lanes that accepted a hit here.
+template <bool STATS, bool FAST, bool ANY, bool CULL>
+YD bool packet_leaf(const DScene &sc, int a, int b, PrimRec p0, bool h, V3 o, V3 u, float &tmax, Hit &hit, Counters &c, int cull_min) {
+  constexpr bool any_hit = ANY;
+  bool got = false;
+  // fat leaf (FAST loops only: every lane NaN-free): most of its primitive steps are settled per packet.
+  // cull_min = YD_CULL_MIN, or INT_MAX when the scene's triangles are not bounded (DScene.boxes_finite bit 1)
+  if (CULL && FAST && a >= cull_min) return leaf_culled<STATS, any_hit>(sc, a, b, h, o, u, tmax, hit, c);
+#ifdef YAHR_PRIO_FAT
+  // a wavefront inside a fat multiLeaf is on a long serial chain: let it issue ahead of its SIMD's other waves
+  if (a >= YAHR_PRIO_FAT) __builtin_amdgcn_s_setprio(3);
+#endif
+  // two primitives per trip, the record buffers swapped: the prefetch of the next record (padded array) never
+  // has to be copied into place (12 SGPR moves per primitive otherwise)
+  PrimRec p1;
+  for (int k = 0; k < a; k += 2) {
+    p1 = load_prim(sc, b + k + 1);
+    if (STATS) c.wave_prims++;
+    got |= test_prim_packet<STATS>(sc, b + k, p0, h & !(any_hit & got), o, u, tmax, hit, c);
+    if (k + 1 >= a) break;
+    p0 = load_prim(sc, b + k + 2);
+    if (STATS) c.wave_prims++;
+    got |= test_prim_packet<STATS>(sc, b + k + 1, p1, h & !(any_hit & got), o, u, tmax, hit, c);
+  }
+#ifdef YAHR_PRIO_FAT
+  if (a >= YAHR_PRIO_FAT) __builtin_amdgcn_s_setprio(0);
+#endif
+  return got;
+}
+
 // One node step of the packet walker: `cur` is node i, the record of node i+1 is requested into `nxt` (padded
 // array: in bounds even for the last node).  Returns the index of the next node (>= n: traversal complete).
 template <bool STATS, bool FAST, bool ADAPT, bool ANY, bool CULL>
@@ -547,34 +587,11 @@ YD int packet_step(const DScene &sc, const NodeRec &cur, NodeRec &nxt, int i, V3
   // ONE wave-uniform branch per node; the slab test is written out in both arms on purpose (testing the
   // leaf flag twice made the compiler carry it as a 64-bit lane mask: ~8 extra scalar instructions per step)
   if (b >= 0) {                                        // leaf
-    PrimRec p0 = load_prim(sc, b), p1;                 // first primitive, requested before the slab test
+    const PrimRec p0 = load_prim(sc, b);               // first primitive, requested before the slab test
     bool h, anyh;
     packet_box<FAST>(cur, on, o, inv, tmax, h, anyh);
     if (anyh) {
-      bool got = false;
-      // fat leaf (FAST loops only: every lane NaN-free): most of its primitive steps are settled per packet.
-      // cull_min = YD_CULL_MIN, or INT_MAX when the scene's triangles are not bounded (DScene.boxes_finite bit 1)
-      if (CULL && FAST && a >= cull_min) got = leaf_culled<STATS, any_hit>(sc, a, b, h, o, u, tmax, hit, c);
-      else {
-#ifdef YAHR_PRIO_FAT
-      // a wavefront inside a fat multiLeaf is on a long serial chain: let it issue ahead of its SIMD's other waves
-      if (a >= YAHR_PRIO_FAT) __builtin_amdgcn_s_setprio(3);
-#endif
-      // two primitives per trip, the record buffers swapped: the prefetch of the next record (padded array) never
-      // has to be copied into place (12 SGPR moves per primitive otherwise)
-      for (int k = 0; k < a; k += 2) {
-        p1 = load_prim(sc, b + k + 1);
-        if (STATS) c.wave_prims++;
-        got |= test_prim_packet<STATS>(sc, b + k, p0, h & !(any_hit & got), o, u, tmax, hit, c);
-        if (k + 1 >= a) break;
-        p0 = load_prim(sc, b + k + 2);
-        if (STATS) c.wave_prims++;
-        got |= test_prim_packet<STATS>(sc, b + k + 1, p1, h & !(any_hit & got), o, u, tmax, hit, c);
-      }
-#ifdef YAHR_PRIO_FAT
-      if (a >= YAHR_PRIO_FAT) __builtin_amdgcn_s_setprio(0);
-#endif
-      }
+      const bool got = packet_leaf<STATS, FAST, ANY, CULL>(sc, a, b, p0, h, o, u, tmax, hit, c, cull_min);
       if (any_hit) {
         if (got) wake = YD_DONE;
         if (wany(got)) {
@@ -595,6 +612,175 @@ YD int packet_step(const DScene &sc, const NodeRec &cur, NodeRec &nxt, int i, V3
     next = anyh ? i + 1 : a;
   }
   return next;
+}
+
+// ---- packets whose rays share ONE direction octant: node steps without the min / max network ------------------
+// bbRayIntersection (AABBs.hs:29-40) takes, per axis, hmin / hmax of the two plane distances t0 = (lo - o) * inv and
+// t1 = (hi - o) * inv.  In the NaN-free regime of the FAST loops (finite lo <= hi, finite o, finite non-zero inv) IEEE
+// subtraction and multiplication are monotone, so for inv > 0:  lo - o <= hi - o  and  t0 <= t1, i.e. hmin(t0, t1) IS
+// t0 and hmax(t0, t1) IS t1 as values (equal values can differ in the sign of a zero only, which neither v_max3 /
+// v_min3 nor the final `tnear > tfar` can see); for inv < 0 the other way round.  96.6 % of the pseudo-bunny's node
+// steps (99 % of the camera and shadow rays', 95 % of the reflection rays'; tools/oct_probe.py) belong to traversals
+// whose active lanes all look into the same octant: then WHICH plane is the near one is a property of the wavefront,
+// the six per-axis v_min / v_max (and the canonicalisation of tMax') disappear -- 29 -> 22 VALU per node step -- and the
+// choice costs no instruction at all if the walk is assembled once per octant: the near / far operands are just other
+// SGPRs of the node record.
+// To keep the eight copies small they hold ONLY the walk from node to node: the run returns when some lane enters a
+// leaf, the leaf's primitives are handled by code that exists once (packet_leaf), and the run is entered again.
+// Mixed-octant wavefronts, the exact (non-FAST) slab form, the adaptive walker and the counting builds keep packet_loop.
+//
+// The run is hand-written gfx950 assembly.  The same walk in C++ (eight instantiations of a templated loop that leaves
+// through its leaf hits) compiled to the 22 VALU but around them the compiler (a) sank the request for the next node
+// below the slab arithmetic, so that every step waited out a scalar-load round trip, and (b) funnelled the loop's exits
+// through flag registers, a dozen scalar instructions per step: 0.360 ms per pseudo-bunny frame against 0.330 without
+// the octant path.  In assembly the request goes out first, and a step is 22 VALU + 6-8 scalar instructions:
+//     s_waitcnt lgkmcnt(0)                 current record (requested one step earlier) is here
+//     s_add / s_lshl / s_load_dwordx8      request node i + 1 into the OTHER record buffer
+//     v_cmp_ge_i32, v_cndmask              on = wake <= i;  tMax' = on ? tMax : -1
+//     6 v_sub, 6 v_mul, v_max (0), v_min (tMax'), v_max3, v_min3, v_cmp_ngt -> vcc = the lanes that enter the box
+//     leaf:      vcc != 0 -> leave (index, count, first primitive, mask);  else on to i + 1
+//     interior:  wake = hit ? wake : max(wake, skip);  vcc != 0 -> i + 1 (already requested);  else request `skip`
+// Two record buffers, the body written twice with their roles swapped (like packet_loop).  No bounds checks: the node
+// array ends in one zeroed padding record, which reads as a leaf without primitives -- walking onto it (i = n) either
+// leaves the run with i = n or steps to n + 1 = skip-free end, so the run ALSO stops at any index >= n (checked on every
+// path that can reach n: after a leaf miss and after a skip).  A skip DRAINS the (now useless) request for i + 1 before it
+// requests its target into the first buffer: in body B that request is in flight into the very same registers, scalar
+// loads return out of order, and the stale record could land last (without the wait the walk ran off the array: a GPU
+// memory fault in round 4).  The records live in fixed registers s[48:55] / s[56:63]
+// (low enough to be allocatable in every kernel: at 8 waves per SIMD the top of the SGPR file is reserved)
+// (an asm operand cannot name the components of a register tuple); the current record is copied in on entry, and the
+// statement drains its last request before it ends, so nothing lands in a register the compiler has taken back.
+// tMax' needs no canonicalisation here: traverse_packet hands over a canonical tMax (a quiet NaN stays "no limit":
+// v_min_f32 returns the other operand).
+#define YD_OCT_BODY(L, NX, FX, NY, FY, NZ, FZ, RA, RB, NXT, CURLO, OTHER)                                   \
+  ".Loct%=_" L ":\n\t"                                                                                       \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                                                 \
+  "s_add_i32 %[nx], %[i], 1\n\t"                                                                             \
+  "s_lshl_b32 %[off], %[nx], 5\n\t"                                                                          \
+  "s_load_dwordx8 " NXT ", %[base], %[off]\n\t"                                                              \
+  "v_cmp_ge_i32_e32 vcc, %[i], %[wake]\n\t"                                                                  \
+  "v_sub_f32_e32 %[t0], " NX ", %[ox]\n\t"                                                                   \
+  "v_sub_f32_e32 %[t2], " NY ", %[oy]\n\t"                                                                   \
+  "v_sub_f32_e32 %[t4], " NZ ", %[oz]\n\t"                                                                   \
+  "v_cndmask_b32_e32 %[t3], -1.0, %[tmax], vcc\n\t"                                                          \
+  "v_sub_f32_e32 %[t1], " FX ", %[ox]\n\t"                                                                   \
+  "v_mul_f32_e32 %[t0], %[t0], %[ix]\n\t"                                                                    \
+  "v_mul_f32_e32 %[t2], %[t2], %[iy]\n\t"                                                                    \
+  "v_mul_f32_e32 %[t4], %[t4], %[iz]\n\t"                                                                    \
+  "v_mul_f32_e32 %[t1], %[t1], %[ix]\n\t"                                                                    \
+  "v_max_f32_e32 %[t4], 0, %[t4]\n\t"                                                                        \
+  "v_max3_f32 %[t0], %[t0], %[t2], %[t4]\n\t"                                                                \
+  "v_sub_f32_e32 %[t2], " FY ", %[oy]\n\t"                                                                   \
+  "v_sub_f32_e32 %[t4], " FZ ", %[oz]\n\t"                                                                   \
+  "v_mul_f32_e32 %[t2], %[t2], %[iy]\n\t"                                                                    \
+  "v_mul_f32_e32 %[t4], %[t4], %[iz]\n\t"                                                                    \
+  "v_min_f32_e32 %[t4], %[t4], %[t3]\n\t"                                                                    \
+  "v_min3_f32 %[t1], %[t1], %[t2], %[t4]\n\t"                                                                \
+  "v_cmp_ngt_f32_e32 vcc, %[t0], %[t1]\n\t"                                                                  \
+  "s_cmp_lt_i32 " RB ", 0\n\t"                                                                               \
+  "s_cbranch_scc0 .Loct%=_" L "_leaf\n\t"                                                                    \
+  "v_max_i32_e32 %[t2], " RA ", %[wake]\n\t"                                                                 \
+  "v_cndmask_b32_e32 %[wake], %[t2], %[wake], vcc\n\t"                                                       \
+  "s_cbranch_vccz .Loct%=_" L "_skip\n\t"                                                                    \
+  "s_mov_b32 %[i], %[nx]\n\t"                                                                                \
+  "s_branch .Loct%=_" OTHER "\n"                                                                             \
+  ".Loct%=_" L "_skip:\n\t"                                                                                  \
+  "s_mov_b32 %[i], " RA "\n\t"                                                                               \
+  "s_cmp_ge_i32 %[i], %[n]\n\t"                                                                              \
+  "s_cbranch_scc1 .Loct%=_end\n\t"                                                                           \
+  "s_lshl_b32 %[off], %[i], 5\n\t"                                                                           \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                                                 \
+  "s_load_dwordx8 s[48:55], %[base], %[off]\n\t"                                                             \
+  "s_branch .Loct%=_A\n"                                                                                     \
+  ".Loct%=_" L "_leaf:\n\t"                                                                                  \
+  "s_cbranch_vccnz .Loct%=_" L "_hit\n\t"                                                                    \
+  "s_mov_b32 %[i], %[nx]\n\t"                                                                                \
+  "s_cmp_ge_i32 %[i], %[n]\n\t"                                                                              \
+  "s_cbranch_scc1 .Loct%=_end\n\t"                                                                           \
+  "s_branch .Loct%=_" OTHER "\n"                                                                             \
+  ".Loct%=_" L "_hit:\n\t"                                                                                   \
+  "s_mov_b32 %[la], " RA "\n\t"                                                                              \
+  "s_mov_b32 %[lb], " RB "\n\t"                                                                              \
+  "s_mov_b64 %[hm], vcc\n\t"                                                                                 \
+  "s_branch .Loct%=_end\n"
+// record in s[48:55] / s[56:63]:  lo.x lo.y lo.z a hi.x hi.y hi.z b
+#define YD_OCT_RUN(NXA, FXA, NYA, FYA, NZA, FZA, NXB, FXB, NYB, FYB, NZB, FZB)                                \
+  asm("s_mov_b32 s48, %[r0]\n\ts_mov_b32 s49, %[r1]\n\ts_mov_b32 s50, %[r2]\n\ts_mov_b32 s51, %[r3]\n\t"     \
+      "s_mov_b32 s52, %[r4]\n\ts_mov_b32 s53, %[r5]\n\ts_mov_b32 s54, %[r6]\n\ts_mov_b32 s55, %[r7]\n"       \
+      YD_OCT_BODY("A", NXA, FXA, NYA, FYA, NZA, FZA, "s51", "s55", "s[56:63]", "s48", "B")                   \
+      YD_OCT_BODY("B", NXB, FXB, NYB, FYB, NZB, FZB, "s59", "s63", "s[48:55]", "s56", "A")                   \
+      ".Loct%=_end:\n\t"                                                                                     \
+      "s_waitcnt lgkmcnt(0)\n"                                                                               \
+      : [i] "+s"(i), [wake] "+v"(wake), [la] "+s"(la), [lb] "+s"(lb), [hm] "+s"(hm), [nx] "=&s"(nx), [off] "=&s"(off),     \
+        [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4)                                    \
+      : [base] "s"(base), [n] "s"(n), [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z), [ix] "v"(inv.x), [iy] "v"(inv.y),      \
+        [iz] "v"(inv.z), [tmax] "v"(tmax), [r0] "s"(A.lo.x), [r1] "s"(A.lo.y), [r2] "s"(A.lo.z), [r3] "s"(A.lo.w),        \
+        [r4] "s"(A.hi.x), [r5] "s"(A.hi.y), [r6] "s"(A.hi.z), [r7] "s"(A.hi.w)                                            \
+      : "vcc", "scc", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61",   \
+        "s62", "s63")
+
+// Walks from node i (record `A`, arrived) until some lane enters a LEAF: returns the leaf's index, with its count and
+// first primitive in la / lb and the lanes that entered it in hm -- or an index >= n when the traversal is complete.
+// tMax cannot change in here (no primitive is tested), wake does.  OCT bit k set: inv component k is negative, the hi
+// plane of that axis is the near one.
+template <int OCT>
+YD int oct_run(const float4 *base, int n, int i, const NodeRec &A, V3 o, V3 inv, float tmax, int &wake, int &la, int &lb,
+               unsigned long long &hm) {
+  int nx, off;
+  float t0, t1, t2, t3, t4;
+#define YD_N(bit, lo, hi) ((OCT & bit) ? hi : lo)
+  // (the operand names must be string literals: one statement per octant)
+  if (OCT == 0) YD_OCT_RUN("s48", "s52", "s49", "s53", "s50", "s54", "s56", "s60", "s57", "s61", "s58", "s62");
+  if (OCT == 1) YD_OCT_RUN("s52", "s48", "s49", "s53", "s50", "s54", "s60", "s56", "s57", "s61", "s58", "s62");
+  if (OCT == 2) YD_OCT_RUN("s48", "s52", "s53", "s49", "s50", "s54", "s56", "s60", "s61", "s57", "s58", "s62");
+  if (OCT == 3) YD_OCT_RUN("s52", "s48", "s53", "s49", "s50", "s54", "s60", "s56", "s61", "s57", "s58", "s62");
+  if (OCT == 4) YD_OCT_RUN("s48", "s52", "s49", "s53", "s54", "s50", "s56", "s60", "s57", "s61", "s62", "s58");
+  if (OCT == 5) YD_OCT_RUN("s52", "s48", "s49", "s53", "s54", "s50", "s60", "s56", "s57", "s61", "s62", "s58");
+  if (OCT == 6) YD_OCT_RUN("s48", "s52", "s53", "s49", "s54", "s50", "s56", "s60", "s61", "s57", "s62", "s58");
+  if (OCT == 7) YD_OCT_RUN("s52", "s48", "s53", "s49", "s54", "s50", "s60", "s56", "s61", "s57", "s62", "s58");
+#undef YD_N
+  return i;
+}
+
+template <bool ANY, bool CULL>
+YD int packet_loop_oct(const DScene &sc, int oct, bool active, V3 o, V3 u, V3 inv, float &tmax, Hit &hit, int &wake, Counters &c) {
+  constexpr bool any_hit = ANY;
+  const int n = sc.n_nodes;
+  wake = active ? 0 : YD_DONE;
+  const int cull_min = (sc.boxes_finite & 2) ? YD_CULL_MIN : 0x7fffffff;   // wave-uniform (leaf_culled)
+  int i = 0;
+  NodeRec A = load_node(sc, 0);
+  for (;;) {
+    int a = 0, b = 0;
+    unsigned long long hm = 0ULL;
+    switch (oct) {                                                        // wave-uniform: one copy of the run per octant
+      case 0: i = oct_run<0>(sc.nodes, n, i, A, o, inv, tmax, wake, a, b, hm); break;
+      case 1: i = oct_run<1>(sc.nodes, n, i, A, o, inv, tmax, wake, a, b, hm); break;
+      case 2: i = oct_run<2>(sc.nodes, n, i, A, o, inv, tmax, wake, a, b, hm); break;
+      case 3: i = oct_run<3>(sc.nodes, n, i, A, o, inv, tmax, wake, a, b, hm); break;
+      case 4: i = oct_run<4>(sc.nodes, n, i, A, o, inv, tmax, wake, a, b, hm); break;
+      case 5: i = oct_run<5>(sc.nodes, n, i, A, o, inv, tmax, wake, a, b, hm); break;
+      case 6: i = oct_run<6>(sc.nodes, n, i, A, o, inv, tmax, wake, a, b, hm); break;
+      default: i = oct_run<7>(sc.nodes, n, i, A, o, inv, tmax, wake, a, b, hm); break;
+    }
+    i = __builtin_amdgcn_readfirstlane(i);                                // (an asm output: tell the compiler it is wave-uniform)
+    if (i >= n) return n;
+    A = load_node(sc, i + 1);                                             // the node after the leaf, requested ahead of its primitives
+    const PrimRec p0 = load_prim(sc, b);
+    const bool h = __builtin_amdgcn_inverse_ballot_w64(hm);
+    const bool got = packet_leaf<false, true, ANY, CULL>(sc, a, b, p0, h, o, u, tmax, hit, c, cull_min);
+    int next = i + 1;
+    if (any_hit) {
+      if (got) wake = YD_DONE;
+      if (wany(got)) {
+        const int m = __builtin_amdgcn_readfirstlane(wave_min_i32(wake));
+        if (m == YD_DONE) return n;
+        if (m > next) { next = m; A = load_node(sc, next); }
+      }
+    }
+    if (next >= n) return n;
+    i = next;
+  }
 }
 
 // The loop body exists twice with the two node buffers swapped: a step to the next node in array order (every
@@ -641,10 +827,28 @@ YD void traverse_packet(const DScene &sc, bool active, bool any_hit, V3 o, V3 u,
   // every node box finite (host check) and no active lane able to form 0*inf or inf-inf in the slab test?
   const bool fast = (sc.boxes_finite & 1) != 0 && !wany(active & !slab_safe(o, inv));
   if (fast && !active) { o = vof(0.0f); inv = vof(1.0f); }     // inactive lanes: NaN-free too (packet_box)
+  // tMax in canonical form (a signalling NaN becomes a quiet one: no comparison and no hmin can tell them apart).  The
+  // octant run's v_min_f32 needs it -- in IEEE mode the instruction answers a signalling NaN with a NaN instead of the
+  // other operand -- and from here on tMax only ever takes computed, i.e. canonical, values.
+  tmax = __builtin_canonicalizef(tmax);
   int wake, i;
   // four copies of the loop (fast/exact slab x closest/first hit), selected once per traversal: run-time flags
   // inside the loop cost scalar instructions on every step
-  if (fast) {
+  // ... and, for packets whose active lanes share one direction octant, the loops without the min / max network
+  bool oct_ok = false; int oct = 0;
+#ifndef YAHR_NO_OCTANT
+  if (CULL && !STATS && !ADAPT && fast) {
+    const unsigned long long act = __builtin_amdgcn_ballot_w64(active);
+    const unsigned long long mx = __builtin_amdgcn_ballot_w64(active & (inv.x < 0.0f)), my = __builtin_amdgcn_ballot_w64(active & (inv.y < 0.0f)),
+                             mz = __builtin_amdgcn_ballot_w64(active & (inv.z < 0.0f));
+    oct_ok = ((mx == 0ULL) | (mx == act)) & ((my == 0ULL) | (my == act)) & ((mz == 0ULL) | (mz == act));
+    oct = (mx != 0ULL ? 1 : 0) | (my != 0ULL ? 2 : 0) | (mz != 0ULL ? 4 : 0);
+  }
+#endif
+  if (CULL && !STATS && !ADAPT && fast && oct_ok) {
+    if (any_hit) i = packet_loop_oct<true, CULL>(sc, oct, active, o, u, inv, tmax, hit, wake, c);
+    else i = packet_loop_oct<false, CULL>(sc, oct, active, o, u, inv, tmax, hit, wake, c);
+  } else if (fast) {
     if (any_hit) i = packet_loop<STATS, true, ADAPT, true, CULL>(sc, active, o, u, inv, tmax, hit, wake, c);
     else i = packet_loop<STATS, true, ADAPT, false, CULL>(sc, active, o, u, inv, tmax, hit, wake, c);
   } else {
@@ -668,9 +872,10 @@ YD void traverse_packet(const DScene &sc, bool active, bool any_hit, V3 o, V3 u,
 // `coherent` (wave-uniform): the rays are camera rays.  The adaptive walker then stays a packet to the end: neighbouring
 // camera rays share almost their whole path, and the hand-off to the lane walker only costs there (1 M triangles, 16 spp,
 // camera rays alone: adaptive 15.6 ms, packet 11.1 ms).  Which walker runs never changes a result.
-// CULL: fat multiLeafs settled per packet (leaf_culled).  Off in the level launches of the wavefront form: those
-// walk the secondary rays of triangle SOUPS (AUTO takes that form for incoherent scenes only), whose packets are too
-// wide for the proof to succeed, and at 64 VGPRs the extra code costs the kernel a dozen spilled registers.
+// CULL: fat multiLeafs settled per packet (leaf_culled) and the octant run for packets that share a direction octant
+// (oct_run).  Off in the level launches of the wavefront form: those walk the secondary rays of triangle SOUPS (AUTO
+// takes that form for incoherent scenes only), whose packets are too wide for the proof to succeed and share an octant
+// in a quarter of their node steps, and at 64 VGPRs the extra code costs the kernel two dozen spilled registers.
 template <int MODE, bool STATS, bool CULL = true>
 YD void traverse(const DScene &sc, bool active, bool any_hit, bool coherent, V3 o, V3 u, float tmax, Hit &hit, Counters &c,
                  int *stk = nullptr, const float4 *pairs = nullptr) {
@@ -1495,7 +1700,8 @@ static void launch_stream_levels(const DScene &sc, const DPairs &dp, SParams sp,
   // the stack walkers keep a per-lane stack of pending right siblings in LDS: stack_levels x 64 entries per wavefront
   size_t lds = (MODE == TRAV_STACK || MODE == TRAV_ADAPT_STACK || MODE == TRAV_ORDERED)
                          ? (size_t)dp.stack_levels * 64 * YD_LEVEL_WAVES * sizeof(int) : 0;
-  if (const char *e = getenv("YAHR_DEBUG_LDS")) lds = (size_t)atoi(e);     // occupancy experiments
+  // occupancy experiments: MORE dynamic LDS than the walker needs (never less: the stack walkers index it by tree level)
+  if (const char *e = getenv("YAHR_DEBUG_LDS")) { const size_t v = (size_t)atoi(e); if (v > lds) lds = v; }
   for (int k = 0; k < sc.depth; ++k) {
     sp.level = k; sp.last = (k == sc.depth - 1) ? 1 : 0;
     hipLaunchKernelGGL(k_sort_scan, dim3(YD_SORT_CELLS / 1024u), dim3(1024), 0, st, sp);

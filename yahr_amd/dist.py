@@ -99,6 +99,11 @@ class ShardPipeline:
         self.n = 0
         self.last = None
         self.on_assembled = None             # optional hook(launch_index, images) on rank 0 (tests)
+        # timing (cuda only; bench.py): per launch an event behind the render and one behind the launch's gather (+ assembly
+        # on rank 0) -- gather_times() turns them into "how long did the exchange step take" and "how much of it was NOT
+        # hidden behind the next launch's render"
+        self.timing = False
+        self.ev_render, self.ev_gathered = {}, {}
 
     def _complete(self, slot):
         """finish the launch occupying `slot`: its gather, and on rank 0 the assembly (on the side stream when
@@ -114,15 +119,21 @@ class ShardPipeline:
                 self.last = self.plan.assemble(gathered, image)
                 if self.on_assembled:
                     self.on_assembled(self.launch[slot], self.last)
-                ev = torch.cuda.Event()
+                ev = torch.cuda.Event(enable_timing=self.timing)
                 ev.record(self.side)
             self.done[slot] = ev
+            if self.timing:
+                self.ev_gathered[self.launch[slot]] = ev
         else:
             work.wait()                                        # (cuda: the render stream waits; cpu: blocks)
             if self.rank == 0:
                 self.last = self.plan.assemble(gathered, image)
                 if self.on_assembled:
                     self.on_assembled(self.launch[slot], self.last)
+            if self.timing and self.cuda:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(torch.cuda.current_stream(self.plan.device))
+                self.ev_gathered[self.launch[slot]] = ev
 
     def submit(self, render_fn):
         slot = self.n & 1
@@ -133,6 +144,10 @@ class ShardPipeline:
         local, gathered, image = self.slots[slot]
         self.launch[slot] = self.n
         render_fn(self.rank, self.plan.world, self.plan.strip_rows, local)
+        if self.timing and self.cuda and self.collective:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream(self.plan.device))
+            self.ev_render[self.n] = ev
         if not self.collective:
             self.last = local[:, : self.plan.height]
             if self.on_assembled:
@@ -153,3 +168,22 @@ class ShardPipeline:
             torch.cuda.current_stream(self.plan.device).wait_stream(self.side)
         self.done = [None, None]
         return self.last if self.rank == 0 else None
+
+    def gather_times(self):
+        """After drain() + a device synchronise, with `timing` set before the launches: per launch (gather_ms, exposed_ms).
+        gather_ms = from the end of the launch's render to the end of its exchange step on this rank (rank 0: gather +
+        assembly on the side stream; other ranks: their send); exposed_ms = the part of it that was not over when the NEXT
+        launch's render ended -- what the exchange step added to the stream of launches (for the last launch: all of it).
+        Without a collective (one rank) there is no exchange step: an empty list."""
+        out = []
+        for i in sorted(self.ev_gathered):
+            if i not in self.ev_render:
+                continue
+            g = self.ev_render[i].elapsed_time(self.ev_gathered[i])
+            nxt = self.ev_render.get(i + 1)
+            e = max(0.0, nxt.elapsed_time(self.ev_gathered[i])) if nxt is not None else g
+            out.append((g, e))
+        return out
+
+    def reset_timing(self):
+        self.ev_render, self.ev_gathered = {}, {}

@@ -763,7 +763,12 @@ YD int packet_loop_oct(const DScene &sc, int oct, bool active, V3 o, V3 u, V3 in
       case 6: i = oct_run<6>(sc.nodes, n, i, A, o, inv, tmax, wake, a, b, hm); break;
       default: i = oct_run<7>(sc.nodes, n, i, A, o, inv, tmax, wake, a, b, hm); break;
     }
-    i = __builtin_amdgcn_readfirstlane(i);                                // (an asm output: tell the compiler it is wave-uniform)
+    // (asm outputs: tell the compiler they are wave-uniform -- it takes them for per-lane values otherwise and builds the
+    // whole leaf code below with exec-masked loops and per-lane gathers of the primitive records)
+    i = __builtin_amdgcn_readfirstlane(i);
+    a = __builtin_amdgcn_readfirstlane(a);
+    b = __builtin_amdgcn_readfirstlane(b);
+    hm = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(hm >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)hm);
     if (i >= n) return n;
     A = load_node(sc, i + 1);                                             // the node after the leaf, requested ahead of its primitives
     const PrimRec p0 = load_prim(sc, b);
@@ -837,7 +842,13 @@ YD void traverse_packet(const DScene &sc, bool active, bool any_hit, V3 o, V3 u,
   // ... and, for packets whose active lanes share one direction octant, the loops without the min / max network
   bool oct_ok = false; int oct = 0;
 #ifndef YAHR_NO_OCTANT
-  if (CULL && !STATS && !ADAPT && fast) {
+  // (not for tiny trees: entering the run costs ~20 scalar instructions per leaf visit -- record copy-in, octant dispatch,
+  // a second request for the node after the leaf -- which only a walk of some length pays back; the 8-sphere scene of
+  // BASELINE config 2, 21 nodes, lost 6 % with it)
+#ifndef YD_OCT_MIN_NODES
+#define YD_OCT_MIN_NODES 64
+#endif
+  if (CULL && !STATS && !ADAPT && fast && n >= YD_OCT_MIN_NODES) {
     const unsigned long long act = __builtin_amdgcn_ballot_w64(active);
     const unsigned long long mx = __builtin_amdgcn_ballot_w64(active & (inv.x < 0.0f)), my = __builtin_amdgcn_ballot_w64(active & (inv.y < 0.0f)),
                              mz = __builtin_amdgcn_ballot_w64(active & (inv.z < 0.0f));
@@ -1013,15 +1024,23 @@ YD V3 material_at(const DScene &sc, int mat, V3 n, V3 dpdu, V3 wi, V3 wo) {
 // LDS and no code for the spill exists.
 // Level slot k (six floats per thread: LDS, or -- DEEP, k >= lds_levels -- this workgroup's slice of the global spill).
 // `in_lds` is wave-uniform; written out per address space so that every access is a plain ds_ / global_ instruction.
+// (LDS pointers carry their address space in the TYPE here: a generic pointer that has been laundered through an asm
+// statement is a FLAT pointer to the compiler -- flat_load / flat_store instead of ds_read / ds_write, three times the
+// vector-memory instructions of the 8-sphere scene before this was noticed)
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(3))) float lfloat;
+#else
+typedef float lfloat;
+#endif
 template <int B>
-YD void slot_put(float *lvl, float *spill, bool in_lds, int k, int lds_levels, int tid, int part, V3 v) {
-  if (in_lds) { float *q = lvl + ((size_t)k * 6 + 3 * part) * B + tid; q[0] = v.x; q[B] = v.y; q[2 * B] = v.z; }
+YD void slot_put(lfloat *lvl, float *spill, bool in_lds, int k, int lds_levels, int tid, int part, V3 v) {
+  if (in_lds) { lfloat *q = lvl + ((size_t)k * 6 + 3 * part) * B + tid; q[0] = v.x; q[B] = v.y; q[2 * B] = v.z; }
   else { float *q = spill + ((size_t)(k - lds_levels) * 6 + 3 * part) * B + tid; q[0] = v.x; q[B] = v.y; q[2 * B] = v.z; }
 }
 template <int B>
-YD V3 slot_get(const float *lvl, const float *spill, bool in_lds, int k, int lds_levels, int tid, int part) {
+YD V3 slot_get(const lfloat *lvl, const float *spill, bool in_lds, int k, int lds_levels, int tid, int part) {
   if (in_lds) {
-    const float *q = lvl + ((size_t)k * 6 + 3 * part) * B + tid;
+    const lfloat *q = lvl + ((size_t)k * 6 + 3 * part) * B + tid;
     asm("" : "+v"(q));                                  // (no forwarding of the stored registers: see radiance)
     return v3(q[0], q[B], q[2 * B]);
   }
@@ -1055,12 +1074,12 @@ YD V3 radiance(const DScene &sc, bool valid, V3 ro_in, V3 rd_in, float *lds, flo
   // LDS is handed out in granules of 1280 bytes on gfx950: 20 floats per thread are 5120 bytes per wavefront = 4 granules,
   // room for 32 wavefronts per CU; the 21st float would cost a fifth granule and leave 25 where the packet kernel wants
   // 28.  So x.x stays in a register (`x_x`) and eight floats are parked.
-  float *park = lds + tid;
-  float *lvl = lds + 8 * B;
+  lfloat *park = (lfloat *)lds + tid;
+  lfloat *lvl = (lfloat *)lds + 8 * B;
   float x_x = 0.0f;
 #define YD_PARK_STORE(x, n, dpdu) { x_x = x.x; park[0] = x.y; park[B] = x.z; park[2 * B] = n.x; park[3 * B] = n.y; \
     park[4 * B] = n.z; park[5 * B] = dpdu.x; park[6 * B] = dpdu.y; park[7 * B] = dpdu.z; }
-#define YD_PARK_LOAD(x, n, dpdu) { const float *pk = park; asm("" : "+v"(pk)); x = v3(x_x, pk[0], pk[B]); \
+#define YD_PARK_LOAD(x, n, dpdu) { const lfloat *pk = park; asm("" : "+v"(pk)); x = v3(x_x, pk[0], pk[B]); \
     n = v3(pk[2 * B], pk[3 * B], pk[4 * B]); dpdu = v3(pk[5 * B], pk[6 * B], pk[7 * B]); }
   if (n_steps > 0) {
     const bool in0 = !DEEP || 0 < lds_levels;
@@ -1149,7 +1168,7 @@ YD V3 radiance(const DScene &sc, bool valid, V3 ro_in, V3 rd_in, float *lds, flo
       v = (w * v) + d;
     }
   for (int k = (DEEP && levels > lds_levels ? lds_levels : levels) - 1; k >= 0; --k) {
-    const float *slot = lvl + (size_t)k * 6 * B + tid;
+    const lfloat *slot = lvl + (size_t)k * 6 * B + tid;
     V3 w = v3(slot[0], slot[B], slot[2 * B]), d = v3(slot[3 * B], slot[4 * B], slot[5 * B]);
     v = (w * v) + d;
   }

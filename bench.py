@@ -166,6 +166,28 @@ def cpu_baseline(desc, cores, spp=1, min_cpu_seconds=10.0, gpu_rows=None):
         (parity_of(gpu_rows(0, img.shape[0]), img) if gpu_rows is not None and img is not None else None)
 
 
+def usable_cores():
+    """Every core this process may use: the scheduler affinity mask, capped by the cgroup's CPU quota when there is one (a
+    container that sees all 256 cores of its host but may run 16 cores' worth of time is a 16-core machine: 256 threads on
+    it measured 10.6 Mrays/s where 16 threads measure 24)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    src = "sched_getaffinity"
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            q = max(1, int(math.ceil(int(quota) / int(period))))
+            if q < n:
+                n, src = q, "cgroup cpu.max (%s / %s) below the affinity mask" % (quota, period)
+    except (OSError, ValueError):
+        try:
+            q, per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()), int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0 and int(math.ceil(q / per)) < n:
+                n, src = int(math.ceil(q / per)), "cgroup cfs quota below the affinity mask"
+        except (OSError, ValueError):
+            pass
+    return n, src
+
+
 def load_profile(workload):
     """Per-frame counter figures of the committed rocprofv3 PMC profile of this workload (profiles/traffic_<workload>.json;
     traffic_latest.json for the headline workload; written by tools/pmc_to_traffic.py from separate --pmc passes), or None."""
@@ -492,7 +514,7 @@ def main():
             "image_checksum": checksum,
         }
         if world == 1 and not args.no_cpu_baseline:
-            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)   # every core this process may use
+            cores, cores_source = usable_cores()
             def gpu_rows(r0, r1):               # the HIP path's rows of the scene camera's frame, same sampler and seed
                 t = torch.zeros((r1 - r0, w, 3), dtype=torch.float32, device=dev)
                 ctx.render_into(t.data_ptr(), r0, r1, yahr_amd.make_opts(traverse=trav, spp=spp, seed=0), stream.cuda_stream)
@@ -501,6 +523,7 @@ def main():
             if args.workload == "scene_fixed":
                 cores = 1                       # configs[0]: "Haskell CPU path single-threaded"
             cb, ost, par = cpu_baseline(desc, cores, spp, gpu_rows=gpu_rows)
+            cb["cores_source"] = cores_source if args.workload != "scene_fixed" else "BASELINE configs[0]: single-threaded"
             out["cpu_baseline"] = cb
             out["parity"] = par
             if ost is not None:

@@ -822,7 +822,7 @@ YD int packet_loop(const DScene &sc, bool active, V3 o, V3 u, V3 inv, float &tma
 // ADAPT: packet while the rays stay coherent, then every lane on its own.  Both halves perform, per ray, the
 // reference's tests in the reference's order, so where the hand-off happens cannot change a result.
 // STK (ADAPT only): the lanes finish on the stack walker when the wavefront may run it (`stk` = the lane's LDS stack)
-template <bool STATS, bool ADAPT, bool STK = false, bool CULL = true>
+template <bool STATS, bool ADAPT, bool STK = false, bool CULL = true, bool OCT = CULL>
 YD void traverse_packet(const DScene &sc, bool active, bool any_hit, V3 o, V3 u, float tmax, Hit &hit, Counters &c,
                         int *stk = nullptr, const float4 *pairs = nullptr) {
   V3 inv = v3(1.0f / u.x, 1.0f / u.y, 1.0f / u.z);
@@ -848,7 +848,7 @@ YD void traverse_packet(const DScene &sc, bool active, bool any_hit, V3 o, V3 u,
 #ifndef YD_OCT_MIN_NODES
 #define YD_OCT_MIN_NODES 64
 #endif
-  if (CULL && !STATS && !ADAPT && fast && n >= YD_OCT_MIN_NODES) {
+  if (OCT && !STATS && !ADAPT && fast && n >= YD_OCT_MIN_NODES) {
     const unsigned long long act = __builtin_amdgcn_ballot_w64(active);
     const unsigned long long mx = __builtin_amdgcn_ballot_w64(active & (inv.x < 0.0f)), my = __builtin_amdgcn_ballot_w64(active & (inv.y < 0.0f)),
                              mz = __builtin_amdgcn_ballot_w64(active & (inv.z < 0.0f));
@@ -856,7 +856,7 @@ YD void traverse_packet(const DScene &sc, bool active, bool any_hit, V3 o, V3 u,
     oct = (mx != 0ULL ? 1 : 0) | (my != 0ULL ? 2 : 0) | (mz != 0ULL ? 4 : 0);
   }
 #endif
-  if (CULL && !STATS && !ADAPT && fast && oct_ok) {
+  if (OCT && !STATS && !ADAPT && fast && oct_ok) {
     if (any_hit) i = packet_loop_oct<true, CULL>(sc, oct, active, o, u, inv, tmax, hit, wake, c);
     else i = packet_loop_oct<false, CULL>(sc, oct, active, o, u, inv, tmax, hit, wake, c);
   } else if (fast) {
@@ -887,14 +887,14 @@ YD void traverse_packet(const DScene &sc, bool active, bool any_hit, V3 o, V3 u,
 // (oct_run).  Off in the level launches of the wavefront form: those walk the secondary rays of triangle SOUPS (AUTO
 // takes that form for incoherent scenes only), whose packets are too wide for the proof to succeed and share an octant
 // in a quarter of their node steps, and at 64 VGPRs the extra code costs the kernel two dozen spilled registers.
-template <int MODE, bool STATS, bool CULL = true>
+template <int MODE, bool STATS, bool CULL = true, bool OCT = CULL>
 YD void traverse(const DScene &sc, bool active, bool any_hit, bool coherent, V3 o, V3 u, float tmax, Hit &hit, Counters &c,
                  int *stk = nullptr, const float4 *pairs = nullptr) {
   if (MODE == TRAV_LANE) traverse_lane<STATS>(sc, active, any_hit, o, u, tmax, hit, c);
   else if (MODE == TRAV_STACK) traverse_stack<STATS, false>(sc, pairs, stk, active, any_hit, o, u, tmax, hit, c);
   else if (MODE == TRAV_ORDERED) traverse_stack<STATS, true>(sc, pairs, stk, active, any_hit, o, u, tmax, hit, c);
-  else if (MODE == TRAV_PACKET) traverse_packet<STATS, false, false, CULL>(sc, active, any_hit, o, u, tmax, hit, c);
-  else if (coherent) traverse_packet<STATS, false, false, CULL>(sc, active, any_hit, o, u, tmax, hit, c);
+  else if (MODE == TRAV_PACKET) traverse_packet<STATS, false, false, CULL, OCT>(sc, active, any_hit, o, u, tmax, hit, c);
+  else if (coherent) traverse_packet<STATS, false, false, CULL, OCT>(sc, active, any_hit, o, u, tmax, hit, c);
   else if (MODE == TRAV_ADAPT_STACK) traverse_packet<STATS, true, true, CULL>(sc, active, any_hit, o, u, tmax, hit, c, stk, pairs);
   else traverse_packet<STATS, true, false, CULL>(sc, active, any_hit, o, u, tmax, hit, c);     // TRAV_ADAPTIVE
 }
@@ -1509,6 +1509,11 @@ __global__ __launch_bounds__(1024) void k_sort_scatter(SParams sp) {
 // in grid-stride order or from an atomic cursor 70+ -- it concentrates the queue-append atomics, and one counter word
 // takes ~90 of them per microsecond).
 #define YD_LEVEL_WAVES 1
+// the shadow rays of a level launch walk as packets (Morton order: neighbours in space, one light): their packets share a
+// direction octant, so they take the octant run (oct_run); the fat-leaf culling stays off in these launches
+#ifndef YD_LEVEL_OCT
+#define YD_LEVEL_OCT 1
+#endif
 template <int MODE, bool STATS>
 __global__ __launch_bounds__(64 * YD_LEVEL_WAVES) __attribute__((amdgpu_waves_per_eu(YAHR_WAVES_LANE, 8)))
 void k_stream_level(DScene sc_in, YD_SCENE_PARAMS_PAIRS, SParams sp, unsigned long long *__restrict__ ctr) {
@@ -1552,7 +1557,7 @@ void k_stream_level(DScene sc_in, YD_SCENE_PARAMS_PAIRS, SParams sp, unsigned lo
     Hit hit;
     // the paths of a wavefront are neighbours in space (Morton order) and a shadow ray's direction follows from its
     // origin: coherent rays, so the adaptive walker stays a packet for them (1 M triangles: 38.3 -> 37.2 ms per frame)
-    traverse<MODE, STATS, false>(sc, active, true, true, qo, qdir, qt, hit, c, stk, a_pairs);
+    traverse<MODE, STATS, false, YD_LEVEL_OCT != 0>(sc, active, true, true, qo, qdir, qt, hit, c, stk, a_pairs);
     if (valid) direct = direct + ((active && hit.prim < 0) ? cv : vof(0.0f));   // sum = foldl (+) 0, light order
   }
   const V3 r = rd - scale(2.0f * dot(rd, n), n);                       // reflectionDir, Integrators.hs:46-47

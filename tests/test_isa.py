@@ -93,9 +93,11 @@ def test_octant_run_is_21_valu_per_node_step(asm):
         assert tail[0].startswith("v_max_i32") and tail[1].startswith("v_cndmask") and tail[2].startswith("s_cbranch_vccz"), tail
         assert len(re.findall(r"v_max3_f32", text)) == 2 and len(re.findall(r"v_min3_f32", text)) == 2       # bodies A and B
         assert len(re.findall(r"v_(min|max)_f32_e32", text)) == 4                                                # max(., 0), min(., tMax')
-    # the counting build keeps the generic loop (its counters are per step), the level launches of the wavefront form too
+    # the counting build keeps the generic loop (its counters are per step); the camera-ray launch of the wavefront form
+    # has the run, and so have its level launches for their shadow rays (first hit only: eight copies)
     assert ".Loct" not in kernel_body(asm, PACKET_STATS)
-    assert ".Loct" not in whole_body(asm, STREAM_LEVEL) and ".Loct" in whole_body(asm, STREAM_PRIMARY)
+    assert ".Loct" in whole_body(asm, STREAM_PRIMARY)
+    assert len(re.findall(r"^\.Loct\d+_A:", whole_body(asm, STREAM_LEVEL), flags=re.M)) == 8
 
 
 def test_no_fma_contraction(asm):
@@ -111,15 +113,15 @@ def test_no_fma_contraction(asm):
 def test_register_budget_and_no_scratch(asm):
     # packet walker (issue bound): 7 waves per SIMD = 72 VGPRs.  The state of the radiance recursion waits in LDS between
     # its uses (render_kernel.hip: radiance), so NOTHING is spilled inside the step loop -- neither in the traversal loops
-    # nor around them.  What remains in scratch memory since the octant run came (round 4) is the pixel's accumulator `acc`
-    # (three dwords per lane, live across the whole sample round): written and read once per sample, outside the step loop.
+    # nor around them, and the kernel of the benchmark touches no scratch memory at all (70 VGPRs since round 4).
     for k in (PACKET_FAST, PACKET_REGROUP):
         m = meta(asm, k)
         assert m["vgpr_count"] <= 72, m
         assert m["vgpr_spill_count"] <= 32, m
         if k != PACKET_FAST:                                     # the regrouping variant is a diagnostics build
             continue
-        assert m["private_segment_fixed_size"] <= 16, m
+        assert m["vgpr_spill_count"] == 0 and m["private_segment_fixed_size"] == 0, m
+        assert "scratch_" not in kernel_body(asm, k)
         lines = kernel_body(asm, k).split("\n")
         # the step loop (depth 2: one traversal per trip) with the traversal loops (depth 3, 4) inside it: from its header
         # to the depth-2 inner loop that follows it (the fold of the radiance levels)
@@ -176,10 +178,10 @@ def test_fat_leaf_culling_code(asm):
     """leaf_culled (render_kernel.hip): the ray-space box of the packet comes from DPP ladders whose cross-lane move rides
     on the v_min / v_max itself (6 instructions per reduction, 12 reductions, in each copy of the leaf code of the NaN-free
     loops: closest hit and first hit, generic loop -- whose body exists twice -- and octant loop);
-    the packet kernel still fits its 72 registers without scratch (test_register_budget_and_no_scratch), and the level
-    launches of the wavefront form, which are built without it, spill nothing any more"""
+    the packet kernel still fits its 72 registers without scratch (test_register_budget_and_no_scratch); the level
+    launches of the wavefront form are built without it (one spilled dword there, as in round 3)"""
     body = kernel_body(asm, PACKET_FAST)
     assert len(re.findall(r"v_min_f32_dpp", body)) == 6 * 36 and len(re.findall(r"v_max_f32_dpp", body)) == 6 * 36
     m = meta(asm, STREAM_LEVEL)
-    assert m["vgpr_spill_count"] == 0 and m["private_segment_fixed_size"] == 0, m
+    assert m["vgpr_spill_count"] <= 1 and m["private_segment_fixed_size"] <= 8, m
     assert "v_min_f32_dpp" not in whole_body(asm, STREAM_LEVEL)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-end evidence on the GPU box: PMC + kernel-trace profiles of the four workloads (-> gpurun_out/prof_<tag>/), then the
 # traffic_<workload>.json files bench.py reads (with the kernel source hash), then the bench lines.  usage: final_profiles.sh <round tag>
-R=${1:-r03}
+R=${1:-r04}
 cd /root/repo
 tools/profile_bench.sh ${R}_bunny --steps 200 --warmup 24 > gpurun_out/prof_${R}_bunny.log 2>&1
 tools/profile_bench.sh ${R}_spheres --workload spheres --steps 200 --warmup 24 > gpurun_out/prof_${R}_spheres.log 2>&1

@@ -312,7 +312,9 @@ int yahr_ctx_set_cameras(yahr_ctx *ctx, int32_t n, const float *cameras);
 int yahr_ctx_stats(yahr_ctx *ctx, yahr_stats *out);
 
 /* Test/diagnostic entry points: run the device functions on arbitrary rays (host buffers, synchronous).
- * rays: n*7 floats (x0, u, tMax).  closest hit -> prim_orig (or -1) and t;  radiance -> n*3 floats. */
+ * rays: n*7 floats (x0, u, tMax).  closest hit -> prim_orig (or -1) and t;  radiance -> n*3 floats.
+ * yahr_ctx_trace / yahr_ctx_occluded run a COUNTING build: their box / triangle / sphere tests are added to the context's
+ * counters (yahr_ctx_stats), so a test can see what a box test decided. */
 int yahr_ctx_trace(yahr_ctx *ctx, int32_t n, const float *rays, int32_t traverse, int32_t *prim_orig, float *t);
 int yahr_ctx_occluded(yahr_ctx *ctx, int32_t n, const float *rays, int32_t traverse, int32_t *blocked);
 int yahr_ctx_radiance(yahr_ctx *ctx, int32_t n, const float *rays, int32_t traverse, float *rgb);

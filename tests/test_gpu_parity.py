@@ -371,6 +371,117 @@ def test_kat_bvh_on_device(gpu, split):
     ctx.close()
 
 
+def _norm32(v):
+    """norm (Vectors.hs:46-47) in binary32: (1 / len v) @* v"""
+    v = np.asarray(v, dtype=np.float32)
+    l = np.sqrt(np.float32((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]), dtype=np.float32)
+    return (np.float32(1.0) / l) * v
+
+
+def test_kat_slab_hits_and_misses_on_device(gpu):
+    """test/Spec.hs:176-218 (AABB "should not be hit by rays missing it" / "should propagate rays intersecting it") on the
+    device's own slab test: a sphere of radius 5 at (15, 25, 35) has exactly the box (10, 20, 30) - (20, 30, 40) of the
+    reference's cases (boundSphere, Spec.hs:110-115), and a one-primitive scene is `wrapCollider col bb` (Culling.hs:33):
+    the box test decides whether the sphere test happens at all.  The diagnostic trace counts its tests, so the outcome of
+    the BOX test is what is asserted -- one box test per ray, and a sphere test exactly for the three rays that enter."""
+    rb = KAT["aabb"]["ray_box"]
+    bs = KAT["bound_sphere"]
+    c = [(a + b) / 2 for a, b in zip(rb["min"], rb["max"])]
+    assert [ci - 5 for ci in c] == rb["min"] and [ci + 5 for ci in c] == rb["max"] and bs["r"] == 5
+    d = scenes.scene_fixed(8, 8).with_(objects=[("sphere", tuple(c), 5.0, "sphere")])
+    scene = d.to_scene().build()
+    a = scene.arrays()
+    assert a["node_lo"].shape[0] == 1 and a["node_lo"][0].tolist() == rb["min"] and a["node_hi"][0].tolist() == rb["max"]
+    ctx = yahr_amd.Context(scene, 0)
+    for mode in TRACE_MODES:
+        for dirs, enters in ((rb["miss_dirs_unnormalised"], 0), (rb["hit_dirs_unnormalised"], 1)):
+            for org, dr in zip(rb["origins"], dirs):
+                ctx.stats()
+                ray = [list(org) + _norm32(dr).tolist() + [1e6]]
+                prim, _ = ctx.trace(ray, mode)
+                st = ctx.stats()
+                assert st["box_tests"] == 1 and st["sphere_tests"] == enters, (mode, org, dr, st["box_tests"], st["sphere_tests"])
+                assert enters or prim[0] == -1
+                blocked = ctx.occluded(ray, mode)
+                st = ctx.stats()
+                assert st["box_tests"] == 1 and st["sphere_tests"] == enters and (enters or blocked[0] == 0)
+    ctx.close()
+
+
+def test_kat_collide_all_order_on_device(gpu):
+    """test/Spec.hs:49-60: collideAll over [Nothing, Just (t = 2), Just (t = 1)] with tMax = 10 yields the hit at t = 1 --
+    `cutRay` shrinks tMax as hits are accepted, and a LATER collider wins an exact tie because the test is `t <= tMax`
+    (Rays.hs:39-46).  On the device as one multiLeaf (BVH depth 0) whose primitives are scanned in stored order."""
+    n = (0.0, 0.0, -1.0)
+
+    def tri(z, x0=-1.0):
+        return ("triangle", (x0, -1.0, z), (x0 + 4.0, -1.0, z), (x0, 3.0, z), n, n, n, "sphere")
+    base = scenes.scene_fixed(8, 8)
+    ray = [[0, 0, 0, 0, 0, 1, 10.0]]
+    cases = [([tri(5.0, x0=50.0), tri(2.0), tri(1.0)], 2, 1.0),            # the reference's case: miss, t = 2, t = 1
+             ([tri(1.0), tri(2.0)], 0, 1.0),                                 # a later, farther hit does not replace it
+             ([tri(1.0), tri(1.0), tri(2.0)], 1, 1.0),                       # exact tie: the later one wins
+             ([tri(1.0), tri(11.0)], 0, 1.0), ([tri(11.0)], -1, 0.0)]        # beyond tMax = 10: no hit
+    for objs, want, t_want in cases:
+        for bvh_depth in (0, 16):
+            ctx = yahr_amd.Context(base.with_(objects=objs, bvh_depth=bvh_depth).to_scene().build(), 0)
+            for mode in TRACE_MODES:
+                prim, t = ctx.trace(ray, mode)
+                assert prim[0] == want and (want < 0 or t[0] == np.float32(t_want)), (want, bvh_depth, mode, prim, t)
+                assert ctx.occluded(ray, mode)[0] == int(want >= 0)
+            ctx.close()
+
+
+def test_kat_blinn_and_integrator_cases_on_device(gpu):
+    """test/Spec.hs:265-328 through yahr_ctx_radiance.  A material with diffuse 0 and specular 1 IS `Blinn e`
+    (Shaders.hs:12-14: 0 * Lambertian + 1 * Blinn), a light of spectrum 1 at distance 1 has intensity 1 (Lights.hs:19),
+    and with recursion depth 1 the reflection term is multiplied by vcast 0 = 0, so the radiance of an eye ray that hits
+    the origin is |l . n| * f(l, eye) -- the BSDF value of the reference's cases up to the known factor |l . n|.
+      * Integrator cases (Spec.hs:265-297): all three are black -- the first and the third because the eye ray travels
+        along +n and collideTriangle culls it (Shapes.hs:57), the second because the light is below the surface;
+      * Blinn "should not transmit" (:316-320): eye above, light below the surface: 0;
+      * Blinn "reflect the most when the angles are equal" (:322-328): f grows over the lights at 0.25, 0.5, 0.75, 0.9 pi.
+    ("should not reflect on the rear side", :310-314, puts the EYE below the surface: as a ray that is a back-face hit,
+    which never reaches the BSDF -- it is black here for the integrator's reason, checked as such.)"""
+    k, b = KAT["integrator"], KAT["bsdf_blinn"]
+    mat = dict(id="blinn", ambient=(0, 0, 0), diffuse=(0, 0, 0), specular=(1, 1, 1), shininess=float(k["exponent"]))
+    nn = tuple(float(x) for x in k["n"])
+    tri = ("triangle", tuple(k["p0"]), tuple(k["p1"]), tuple(k["p2"]), nn, nn, nn, "blinn")
+
+    def vec(a):
+        return np.array([math.cos(a * math.pi), 0.0, math.sin(a * math.pi)])
+
+    def radiance(light_pos, ray, mode):
+        d = scenes.scene_fixed(8, 8).with_(objects=[tri], materials=[mat], lights=[(tuple(light_pos), (1, 1, 1))], depth=1, bvh_depth=16)
+        ctx = yahr_amd.Context(d.to_scene().build(), 0)
+        out = ctx.radiance([ray], mode)[0]
+        ref = OracleScene.from_desc(d).build().radiance(np.array(ray, dtype=np.float32))
+        ctx.close()
+        assert outside_tol(out[None, None], np.asarray(ref, dtype=np.float32)[None, None]) == 0
+        return out
+
+    def eye(a):                                       # Spec.hs: eye angle = Ray (negate (vec angle)) (vec angle)
+        return list(-vec(a)) + list(vec(a)) + [1e6]
+    for mode in (yahr_amd.TRAVERSE_LANE, yahr_amd.TRAVERSE_PACKET):
+        # Integrator, "should not reflect on the rear side"
+        assert near(radiance(vec(0.25), [0, 0, -1, 0, 0, 1, 1e6], mode), [0, 0, 0])
+        assert near(radiance(-vec(0.25), eye(1.5), mode), [0, 0, 0])
+        # Integrator, "should reflect the most ...": every value is 0 (eye ray along +n), so the list is sorted
+        rads = [float((radiance(-vec(a), eye(0.25), mode) ** 2).sum()) for a in (0.25, 0.5, 0.75)]
+        assert rads == sorted(rads) == [0.0, 0.0, 0.0]
+        # Blinn: the eye at `eye_a` above the surface looks at the origin; the light sits at distance 1 in direction `a`
+        cam = lambda eye_a: list(vec(eye_a)) + list(-vec(eye_a)) + [1e6]
+        for a in b["no_transmission"]["lights"]:
+            assert near(radiance(vec(a), cam(b["no_transmission"]["eye"]), mode), b["no_transmission"]["out"])
+        assert near(radiance(vec(b["rear"]["light"]), cam(b["rear"]["eye"]), mode), b["rear"]["out"])
+        fs = []
+        for a in b["monotone"]["lights"]:
+            r = radiance(vec(a), cam(b["monotone"]["eye"]), mode)
+            assert r[0] == r[1] == r[2] and r[0] > 0
+            fs.append(float(r[0]) / abs(math.sin(a * math.pi)))           # / |l . n|
+        assert fs == sorted(fs) and fs[-1] > fs[0] > 0, fs
+
+
 def test_radiance_entry_point_matches_oracle(gpu):
     d = scenes.scene_fixed(8, 8)
     ctx = yahr_amd.Context(d.to_scene().build(), 0)

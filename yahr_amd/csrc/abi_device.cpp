@@ -901,7 +901,7 @@ static int ray_query(yahr_ctx *c, int32_t n, const float *rays, int which, int t
     if (walker) { mode = walker; int rc = ensure_pairs(c); if (rc) return rc; }
     HIP_TRY(d_i.alloc(sizeof(int) * (size_t)n));
     HIP_TRY(d_f.alloc(sizeof(float) * (size_t)n));
-    HIP_TRY(yahr_dev::launch_trace(c->ds, c->dp, mode, n, d_rays.as<float>(), which == 1, d_i.as<int>(), d_f.as<float>(), nullptr));
+    HIP_TRY(yahr_dev::launch_trace(c->ds, c->dp, mode, n, d_rays.as<float>(), which == 1, d_i.as<int>(), d_f.as<float>(), c->d_ctr, nullptr));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(iout, d_i.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
     if (fout) HIP_TRY(hipMemcpy(fout, d_f.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));

@@ -1634,9 +1634,12 @@ __global__ __launch_bounds__(256) void k_stream_resolve_lanes(RParams rp, SParam
 }
 
 // ---- diagnostic kernels: device functions on arbitrary rays (KAT checks on the GPU) -----------------
+// (a COUNTING build: the diagnostic ray queries add their box / primitive tests to the context's counters, so a test
+// can see what a box test decided -- a ray that enters a leaf's box costs a primitive test, one that misses it does not)
 template <int MODE>
 __global__ __launch_bounds__(64) void k_trace(DScene sc_in, YD_SCENE_PARAMS_PAIRS, int n, const float *__restrict__ rays,
-                                              int any_hit, int *__restrict__ prim_out, float *__restrict__ t_out) {
+                                              int any_hit, int *__restrict__ prim_out, float *__restrict__ t_out,
+                                              unsigned long long *__restrict__ ctr) {
   extern __shared__ int trav_stack[];
   YD_SCENE_BIND
   const int i = blockIdx.x * 64 + threadIdx.x;
@@ -1644,11 +1647,12 @@ __global__ __launch_bounds__(64) void k_trace(DScene sc_in, YD_SCENE_PARAMS_PAIR
   V3 o = vof(0.0f), d = v3(0, 0, 1); float tmax = 0.0f;
   if (valid) { const float *p = rays + 7 * (size_t)i; o = v3(p[0], p[1], p[2]); d = v3(p[3], p[4], p[5]); tmax = p[6]; }
   Hit h; Counters c = {};
-  traverse<MODE, false>(sc, valid, any_hit != 0, false, o, d, tmax, h, c, trav_stack + threadIdx.x, a_pairs);
+  traverse<MODE, true>(sc, valid, any_hit != 0, false, o, d, tmax, h, c, trav_stack + threadIdx.x, a_pairs);
   if (valid) {
     prim_out[i] = h.prim >= 0 ? __float_as_int(sc.prims[3 * (size_t)h.prim + 2].w) : -1;
     if (t_out) t_out[i] = h.t;
   }
+  flush_counters(c, ctr, threadIdx.x & 63);
 }
 
 // radiance of arbitrary rays; tMax of the given ray is ignored (the integrator casts with 1e6, like vcast)
@@ -1762,10 +1766,10 @@ hipError_t launch_stream_pass(const DScene &sc, const DPairs &dp, const RParams 
 }
 
 hipError_t launch_trace(const DScene &sc, const DPairs &dp, int mode, int n, const float *rays, int any_hit, int *prim_out,
-                        float *t_out, hipStream_t st) {
+                        float *t_out, unsigned long long *ctr, hipStream_t st) {
   const int nb = (n + 63) / 64;
   const size_t lds = (size_t)dp.stack_levels * 64 * sizeof(int);
-#define YD_TRACE(M, L) hipLaunchKernelGGL((k_trace<M>), dim3(nb), dim3(64), L, st, sc, sc.nodes, sc.prims, sc.normals, dp.pairs, dp.stack_levels, n, rays, any_hit, prim_out, t_out)
+#define YD_TRACE(M, L) hipLaunchKernelGGL((k_trace<M>), dim3(nb), dim3(64), L, st, sc, sc.nodes, sc.prims, sc.normals, dp.pairs, dp.stack_levels, n, rays, any_hit, prim_out, t_out, ctr)
   switch (mode) {
     case TRAV_LANE: YD_TRACE(TRAV_LANE, 0); break;
     case TRAV_STACK: YD_TRACE(TRAV_STACK, lds); break;

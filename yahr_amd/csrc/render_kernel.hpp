@@ -127,7 +127,7 @@ namespace yahr_dev {
 hipError_t launch_render(const DScene &sc, const RParams &rp, int mode, bool regroup, int n_blocks, float *out,
                          unsigned long long *ctr, bool stats, hipStream_t st);
 hipError_t launch_trace(const DScene &sc, const DPairs &dp, int mode, int n, const float *rays, int any_hit, int *prim_out,
-                        float *t_out, hipStream_t st);
+                        float *t_out, unsigned long long *ctr, hipStream_t st);
 hipError_t launch_radiance(const DScene &sc, int mode, int n, const float *rays, float *rgb,
                            unsigned long long *ctr, float *lvl_spill, int lds_levels, hipStream_t st);
 hipError_t launch_warmup(hipStream_t st);          // an empty kernel: makes the runtime load this library's code object

@@ -1436,16 +1436,69 @@ def test_device_bvh_leaf_boxes_in_a_stride_loop(gpu, monkeypatch):
         monkeypatch.delenv("YAHR_BVH_LEAF_BLOCKS")
 
 
+@pytest.mark.parametrize("case", ["sphere_grid", "bunny16", "bunny3", "tris200k_d16", "tris1m_d20", "grid_d24", "spheres_mix"])
+def test_device_bvh_build_sah_is_the_host_tree(gpu, case, tris1m):
+    """sahSplit (Culling.hs:62-112) on the device builder: 16 bucket counts and boxes per node from atomics, wrappedArea
+    and the 15 costs in the reference's fold order, minimumBy with its NaN behaviour, `length xs > 4` else the midpoint --
+    node array (boxes with their zero signs, skip links, leaf ranges) and leaf order bit for bit the host builder's, on
+    the reference's own 200-sphere grid (Spec.hs:221-262), the pseudo-bunny, shallow trees, a 200 k soup, the 1 M-triangle
+    scene, a grid soup full of ties and coincident primitives (empty buckets: wrappedArea = +inf) and spheres mixed in."""
+    if case == "sphere_grid":
+        d = scenes.spec_sphere_grid("SurfaceAreaHeuristic")
+    elif case == "bunny16":
+        d = scenes.pseudo_bunny(32, 18, split="SurfaceAreaHeuristic")
+    elif case == "bunny3":
+        d = scenes.pseudo_bunny(32, 18, bvh_depth=3, split="SurfaceAreaHeuristic")
+    elif case == "tris200k_d16":
+        d = scenes.random_tris(200_000, 32, 18, bvh_depth=16).with_(split="SurfaceAreaHeuristic")
+    elif case == "tris1m_d20":
+        d = tris1m.with_(split="SurfaceAreaHeuristic")
+    elif case == "grid_d24":
+        d = scenes.random_tris(8, 16, 16).with_(objects=[_grid_soup(50_000, 5)], bvh_depth=24, split="SurfaceAreaHeuristic")
+    else:
+        base = scenes.random_tris(40_000, 16, 16, bvh_depth=18, seed=3)
+        rng = np.random.default_rng(4)
+        sph = [("sphere", tuple(rng.uniform(-9, 9, 3)), float(rng.uniform(0.01, 0.5)), "tri") for _ in range(3000)]
+        d = base.with_(objects=base.objects + sph, split="SurfaceAreaHeuristic")
+    host = d.to_scene().set_builder(yahr_amd.BUILDER_HOST).build()
+    dev = d.to_scene().set_builder(yahr_amd.BUILDER_DEVICE).build()
+    assert host.builder_used()[0] == yahr_amd.BUILDER_HOST
+    used, ms = dev.builder_used()
+    assert used == yahr_amd.BUILDER_DEVICE and ms > 0
+    print(f"SAH {case}: {dev.flat.contents.n_prims} primitives, {dev.flat.contents.n_nodes} nodes, device build {ms:.2f} ms")
+    assert _same_flat_scene(host.arrays(), dev.arrays()) is None
+    if case == "tris1m_d20":
+        assert ms <= 10.0, ms
+
+
+def test_device_bvh_build_sah_fuzz(gpu):
+    """the fuzz of the midpoint builder with the surface-area heuristic: grid coordinates (ties, signed zeros, coincident
+    primitives, buckets that stay empty), spheres, repeated primitives, 2 .. 3000 primitives, depth 1 .. 24"""
+    for seed in range(120):
+        rng = np.random.default_rng(7000 + seed)
+        n = int(rng.choice([2, 3, 5, 6, 17, 64, 65, 300, 1025, 3000]))
+        objs = [_grid_soup(n, seed)] if seed % 3 else []
+        if seed % 3 == 0 or seed % 5 == 0:
+            for _ in range(n):
+                c = tuple((rng.integers(-4, 5, 3) * 0.5).tolist()) if seed % 2 else tuple(rng.uniform(-3, 3, 3).tolist())
+                objs.append(("sphere", c, float(rng.choice([0.0, 0.25, 0.5, 1.0])), "tri"))
+        if seed % 7 == 0:
+            objs = objs + objs[:1]
+        d = scenes.random_tris(8, 16, 16).with_(objects=objs, bvh_depth=int(rng.integers(1, 25)), split="SurfaceAreaHeuristic")
+        host = d.to_scene().set_builder(yahr_amd.BUILDER_HOST).build()
+        dev = d.to_scene().set_builder(yahr_amd.BUILDER_DEVICE).build()
+        assert dev.builder_used()[0] == yahr_amd.BUILDER_DEVICE
+        assert _same_flat_scene(host.arrays(), dev.arrays()) is None, seed
+
+
 def test_device_bvh_build_declines_what_it_cannot_do(gpu):
-    """SAH, non-finite boxes and tiny scenes stay with the host builder under AUTO; naming the device builder for them
-    is an error, not a different tree"""
+    """non-finite boxes and tiny scenes stay with the host builder under AUTO; naming the device builder for a scene it
+    cannot build is an error, not a different tree.  (Both split modes are built on the device since round 4.)"""
     d = scenes.random_tris(40_000, 16, 16, bvh_depth=12)
     s = d.with_(split="SurfaceAreaHeuristic").to_scene().build()
-    assert s.builder_used()[0] == yahr_amd.BUILDER_HOST
+    assert s.builder_used()[0] == yahr_amd.BUILDER_DEVICE                             # AUTO, 40 000 primitives, SAH
     assert d.to_scene().build().builder_used()[0] == yahr_amd.BUILDER_DEVICE          # AUTO, 40 000 primitives
     assert scenes.scene_fixed(16, 16).to_scene().build().builder_used()[0] == yahr_amd.BUILDER_HOST
-    with pytest.raises(yahr_amd.YahrError):
-        d.with_(split="SurfaceAreaHeuristic").to_scene().set_builder(yahr_amd.BUILDER_DEVICE).build()
     inf = d.with_(objects=d.objects + [("sphere", (0.0, 0.0, 0.0), float("inf"), "tri")])
     assert inf.to_scene().build().builder_used()[0] == yahr_amd.BUILDER_HOST
     with pytest.raises(yahr_amd.YahrError):

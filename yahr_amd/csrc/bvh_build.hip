@@ -14,9 +14,22 @@
 //   afterwards: leaf boxes (join of the primitives' boxes in leaf order, Haskell's min / max: on a tie the FIRST wins a
 //               min and the LAST a max -- that is what decides the sign of a zero, and it is reproduced), bottom-up
 //               subtree sizes and interior boxes (join left right, Culling.hs:39), top-down DFS indices, emit.
-// Inputs must be NaN-free and finite (the host checks and otherwise builds on the CPU); the surface-area heuristic stays
-// on the host.  A partition that puts nothing on the left (only possible when halving a subnormal rounds) aborts the
-// device build, and the host builds instead.
+// Inputs must be NaN-free and finite (the host checks and otherwise builds on the CPU).  A partition that puts nothing on
+// the left (only possible when halving a subnormal rounds) aborts the device build, and the host builds instead.
+//
+// The surface-area heuristic (sahSplit, Culling.hs:62-112; round 4) fits the same scheme: it only replaces the FLAG of a
+// node with more than four items -- `bucketId <= split` instead of `centroid <= mid`:
+//   k_decide       also hands the node a bucket slot and keeps centMin / centMax of the split axis
+//   k_sah_init     16 x (count, box) per slot: 0 and AABBs.empty
+//   k_sah_buckets  every item into its bucket: count + 1, box joined (atomics on order-preserving keys; a workgroup that
+//                  holds one node collects in LDS first)
+//   k_sah_pick     wrappedArea, the 15 costs from prefix / suffix joins in the reference's fold order, minimumBy
+//                  (with its NaN behaviour: compare is GT for unordered operands) -- one thread per node
+// Bucket boxes come out of atomics instead of an ordered fold, so they may differ from the host's in the SIGN OF A ZERO
+// (Haskell's min keeps the first of two equal values, max the last).  No decision can see that: a zero extent times a
+// count is a zero of either sign, sums and 0.125 + x absorb it, 0 / wrappedArea is a NaN or a zero whatever the sign,
+// and wrappedArea itself is a sum that starts at +0.  The boxes that END UP in the tree are formed afterwards, in leaf
+// order, exactly as for the midpoint tree.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -39,6 +52,7 @@ struct BNode {                       // a node while the tree grows, in creation
   int dim; float mid; int nl;
   float lo[3], hi[3];                // box (leaves: from the primitives; interior: join of the children)
   int size, idx;                     // nodes of the subtree; DFS index
+  int slot, best; float cmin, cmax;  // surface-area heuristic: bucket slot (-1: midpoint split), chosen split, centMin / centMax
 };
 
 __device__ __forceinline__ int fkey(float f) { int k = __float_as_int(f); return k ^ ((k >> 31) & 0x7fffffff); }
@@ -59,6 +73,7 @@ __device__ __forceinline__ void node_reset(BNode &nd, int first, int count, int 
   nd.first = first; nd.count = count; nd.left = -1; nd.level = level; nd.dim = -1; nd.mid = 0.0f; nd.nl = 0;
   nd.cb[0] = nd.cb[1] = nd.cb[2] = 0x7fffffff; nd.cb[3] = nd.cb[4] = nd.cb[5] = (int)0x80000000;
   nd.size = 1; nd.idx = 0;
+  nd.slot = -1; nd.best = 0; nd.cmin = nd.cmax = 0.0f;
 }
 __global__ void k_root(BNode *nodes, int n, int *n_nodes) { node_reset(nodes[0], 0, n, 0); *n_nodes = 1; }
 
@@ -117,7 +132,7 @@ __global__ __launch_bounds__(BT) void k_bounds(int n, int level, const float4 *_
   }
 }
 
-__global__ void k_decide(int n0, int n1, int level, BNode *nodes) {
+__global__ void k_decide(int n0, int n1, int level, BNode *nodes, int sah, int *n_slots) {
   const int j = n0 + blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n1) return;
   BNode &nd = nodes[j];
@@ -128,11 +143,116 @@ __global__ void k_decide(int n0, int n1, int level, BNode *nodes) {
   const int d = (ex > ey && ex > ez) ? 0 : (ey > ez ? 1 : 2);            // maxDimension, Vectors.hs:55-66
   nd.dim = d;
   nd.mid = 0.5f * lo[d] + 0.5f * hi[d];                                   // dim d (centroid bounds)
+  if (sah && nd.count > 4) {                                              // `length xs > 4` (Culling.hs:110), else midpointSplit
+    nd.cmin = lo[d]; nd.cmax = hi[d];
+    nd.slot = atomicAdd(n_slots, 1);
+  }
+}
+
+// ---- sahSplit (Culling.hs:62-112) ----------------------------------------------------------------------------------
+#define NBK 16
+#define SLOT_WORDS (NBK * 7)         /* per bucket: count, box as keys (min x y z, max x y z) */
+__device__ __forceinline__ int bucket_id(float c, float cmin, float cmax) {          // Culling.hs:69-79
+  const float length = cmax - cmin;
+  const float dd = c - cmin;
+  const float frac = dd / length;
+  const float v = 16.0f * frac;
+  // GHC's floor :: Float -> Int of a NaN or an infinity is minBound, then `max 0` -> 0
+  int fl = (v != v || fabsf(v) == __builtin_huge_valf()) ? 0 : (int)fminf(fmaxf(floorf(v), -1.0f), 16.0f);
+  if (fl < 0) fl = 0;
+  if (fl > NBK - 1) fl = NBK - 1;
+  return fl;
+}
+__device__ __forceinline__ float comp(float4 c, int d) { return d == 0 ? c.x : (d == 1 ? c.y : c.z); }
+
+__global__ void k_sah_init(const int *__restrict__ n_slots, int *__restrict__ slots) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)*n_slots * SLOT_WORDS) return;
+  const int w = (int)(t % 7);
+  slots[t] = w == 0 ? 0 : (w <= 3 ? fkey(__builtin_huge_valf()) : fkey(-__builtin_huge_valf()));   // count 0, AABBs.empty
+}
+
+__global__ __launch_bounds__(BT) void k_sah_buckets(int n, int level, const float4 *__restrict__ items, const int *__restrict__ seg,
+                                                    const BNode *__restrict__ nodes, const float *__restrict__ boxes,
+                                                    int *__restrict__ slots) {
+  __shared__ int sh[SLOT_WORDS];
+  __shared__ int sh_same;
+  const int i = blockIdx.x * BT + threadIdx.x;
+  const bool valid = i < n;
+  const int j = valid ? seg[i] : -1;
+  const bool act = valid && splittable(nodes[j], level) && nodes[j].slot >= 0;
+  // a workgroup whose items all belong to ONE node (near the root: nearly always) collects in LDS and flushes once
+  const int block_nd = seg[min((int)(blockIdx.x * BT), n - 1)];
+  if (threadIdx.x == 0) sh_same = 1;
+  for (int w = threadIdx.x; w < SLOT_WORDS; w += BT) { const int k = w % 7; sh[w] = k == 0 ? 0 : (k <= 3 ? fkey(__builtin_huge_valf()) : fkey(-__builtin_huge_valf())); }
+  __syncthreads();
+  if (valid && j != block_nd) sh_same = 0;                                // (benign race: every writer writes 0)
+  __syncthreads();
+  const bool same = sh_same != 0;
+  if (act) {
+    const BNode &nd = nodes[j];
+    const float4 c = items[i];
+    const int b = bucket_id(comp(c, nd.dim), nd.cmin, nd.cmax);
+    const float *bx = boxes + 6 * (size_t)__float_as_int(c.w);
+    int *dst = same ? sh + 7 * b : slots + (size_t)nd.slot * SLOT_WORDS + 7 * b;
+    atomicAdd(dst, 1);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { atomicMin(dst + 1 + k, fkey(bx[k])); atomicMax(dst + 4 + k, fkey(bx[3 + k])); }
+  }
+  if (same) {
+    __syncthreads();
+    const BNode &nd = nodes[block_nd];
+    if (splittable(nd, level) && nd.slot >= 0)
+      for (int w = threadIdx.x; w < SLOT_WORDS; w += BT) {
+        const int k = w % 7, v = sh[w];
+        int *dst = slots + (size_t)nd.slot * SLOT_WORDS + w;
+        if (k == 0) { if (v) atomicAdd(dst, v); } else if (k <= 3) atomicMin(dst, v); else atomicMax(dst, v);
+      }
+  }
+}
+
+struct BBox { float lo[3], hi[3]; };
+__device__ __forceinline__ BBox bb_empty() { const float inf = __builtin_huge_valf(); return BBox{{inf, inf, inf}, {-inf, -inf, -inf}}; }
+__device__ __forceinline__ BBox bb_join(BBox a, BBox b) {                 // AABBs.hs:25-27
+  BBox r;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { r.lo[k] = hmin(a.lo[k], b.lo[k]); r.hi[k] = hmax(a.hi[k], b.hi[k]); }
+  return r;
+}
+__device__ __forceinline__ float bb_surf(BBox b) {                         // AABBs.hs:51-53
+  const float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+  return 2.0f * ((dx * dy + dx * dz) + dy * dz);
+}
+__global__ void k_sah_pick(int n0, int n1, int level, BNode *nodes, const int *__restrict__ slots) {
+  const int j = n0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n1) return;
+  BNode &nd = nodes[j];
+  if (!splittable(nd, level) || nd.slot < 0) return;
+  const int *sl = slots + (size_t)nd.slot * SLOT_WORDS;
+  int cnt[NBK]; BBox bbs[NBK];
+  for (int b = 0; b < NBK; ++b) {
+    cnt[b] = sl[7 * b];
+    for (int k = 0; k < 3; ++k) { bbs[b].lo[k] = fkey_inv(sl[7 * b + 1 + k]); bbs[b].hi[k] = fkey_inv(sl[7 * b + 4 + k]); }
+  }
+  float wrapped = 0.0f;                                                    // foldl (\x (_, bb) -> x + surf bb) 0 buckets
+  for (int b = 0; b < NBK; ++b) wrapped = wrapped + bb_surf(bbs[b]);
+  int best_i = 0; float best_c = 0.0f;
+  for (int i = 0; i <= NBK - 2; ++i) {                                     // costOfSplitAt i, splitIds = [0 .. nBuckets - 2]
+    BBox b0 = bb_empty(), b1 = bb_empty(); int c0 = 0, c1 = 0;
+    for (int k = 0; k <= i; ++k) { b0 = bb_join(b0, bbs[k]); c0 += cnt[k]; }
+    for (int k = i + 1; k < NBK; ++k) { b1 = bb_join(b1, bbs[k]); c1 += cnt[k]; }
+    const float cost = 0.125f + ((float)c0 * bb_surf(b0) + (float)c1 * bb_surf(b1)) / wrapped;
+    // minimumBy (compare `on` snd): keep x unless compare x y == GT, and compare is GT when x > y or the two are unordered
+    if (i == 0) { best_i = 0; best_c = cost; }
+    else if (!(best_c < cost) && !(best_c == cost)) { best_i = i; best_c = cost; }
+  }
+  nd.best = best_i;
 }
 
 __device__ __forceinline__ unsigned flag_of(const BNode &nd, int level, float4 c) {
   if (!splittable(nd, level)) return 0u;
   const float v = nd.dim == 0 ? c.x : (nd.dim == 1 ? c.y : c.z);
+  if (nd.slot >= 0) return bucket_id(v, nd.cmin, nd.cmax) <= nd.best ? 1u : 0u;      // partition ((<= split) . bucketId), Culling.hs:111
   return v <= nd.mid ? 1u : 0u;                                           // midpointSplit: `<=` goes left (Culling.hs:56-60)
 }
 
@@ -304,7 +424,7 @@ namespace yahr {
 
 // boxes: n x {lo xyz, hi xyz}, finite.  On success fills `nodes` (DFS order) and `order` (leaf order: primitive ids) and
 // returns true; returns false (with the reason in *why) when the device build cannot be used -- nothing is written then.
-bool device_build_bvh(const float *boxes, int32_t n, int max_depth, std::vector<yahr_node> &nodes, std::vector<int32_t> &order,
+bool device_build_bvh(const float *boxes, int32_t n, int max_depth, int split, std::vector<yahr_node> &nodes, std::vector<int32_t> &order,
                       double *device_ms, std::string *why) {
   auto fail = [&](const std::string &m) { if (why) *why = m; return false; };
   if (n < 2 || max_depth < 0) return fail("nothing to split");
@@ -314,12 +434,15 @@ bool device_build_bvh(const float *boxes, int32_t n, int max_depth, std::vector<
   if (hipGetDevice(&dev) != hipSuccess) return fail("hipGetDevice failed");
   Dev mem;
   float *d_boxes; float4 *it[2]; int *sg[2]; BNode *d_nodes; unsigned *d_local, *d_tot; int *d_cnt; yahr_node *d_out; int *d_order;
+  int *d_slots = nullptr;
+  const bool sah = split == YAHR_SPLIT_SAH;
+  const size_t cap_slots = (size_t)n / 5 + 1;                            // the nodes of one level with more than four items
   const int nb = (n + BT - 1) / BT;
   const size_t cap = 2 * (size_t)n;                                      // every split makes two non-empty children: < 2 n nodes
   if (!mem.alloc(&d_boxes, 6 * (size_t)n) || !mem.alloc(&it[0], (size_t)n) || !mem.alloc(&it[1], (size_t)n) ||
       !mem.alloc(&sg[0], (size_t)n) || !mem.alloc(&sg[1], (size_t)n) || !mem.alloc(&d_nodes, cap) ||
-      !mem.alloc(&d_local, (size_t)n) || !mem.alloc(&d_tot, (size_t)nb + 1) || !mem.alloc(&d_cnt, 2) ||
-      !mem.alloc(&d_out, cap) || !mem.alloc(&d_order, (size_t)n))
+      !mem.alloc(&d_local, (size_t)n) || !mem.alloc(&d_tot, (size_t)nb + 1) || !mem.alloc(&d_cnt, 3) ||
+      !mem.alloc(&d_out, cap) || !mem.alloc(&d_order, (size_t)n) || (sah && !mem.alloc(&d_slots, cap_slots * SLOT_WORDS)))
     return fail("out of device memory");
   hipEvent_t e0 = nullptr, e1 = nullptr;
   struct Ev { hipEvent_t &a, &b; ~Ev() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); } } evs{e0, e1};
@@ -328,7 +451,7 @@ bool device_build_bvh(const float *boxes, int32_t n, int max_depth, std::vector<
 #define LAUNCH(...) do { hipLaunchKernelGGL(__VA_ARGS__); BV(hipGetLastError()); } while (0)
   BV(hipEventCreate(&e0)); BV(hipEventCreate(&e1));
   BV(hipMemcpy(d_boxes, boxes, sizeof(float) * 6 * (size_t)n, hipMemcpyHostToDevice));
-  BV(hipMemset(d_cnt, 0, sizeof(int) * 2));
+  BV(hipMemset(d_cnt, 0, sizeof(int) * 3));
   BV(hipEventRecord(e0, nullptr));
   LAUNCH(k_items, dim3(nb), dim3(BT), 0, nullptr, n, d_boxes, it[0], sg[0]);
   LAUNCH(k_root, dim3(1), dim3(1), 0, nullptr, d_nodes, n, d_cnt);
@@ -339,7 +462,15 @@ bool device_build_bvh(const float *boxes, int32_t n, int max_depth, std::vector<
     if (n1 == n0) break;
     const int gb = (n1 - n0 + 255) / 256;
     LAUNCH(k_bounds, dim3(nb), dim3(BT), 0, nullptr, n, level, it[cur], sg[cur], d_nodes);
-    LAUNCH(k_decide, dim3(gb), dim3(256), 0, nullptr, n0, n1, level, d_nodes);
+    if (sah) BV(hipMemsetAsync(d_cnt + 2, 0, sizeof(int), nullptr));
+    LAUNCH(k_decide, dim3(gb), dim3(256), 0, nullptr, n0, n1, level, d_nodes, sah ? 1 : 0, d_cnt + 2);
+    if (sah) {
+      // at most min(nodes of the level, n / 5 + 1) slots; the kernels read the count on the device
+      const size_t max_slots = std::min<size_t>((size_t)(n1 - n0), cap_slots);
+      LAUNCH(k_sah_init, dim3((unsigned)((max_slots * SLOT_WORDS + 255) / 256)), dim3(256), 0, nullptr, d_cnt + 2, d_slots);
+      LAUNCH(k_sah_buckets, dim3(nb), dim3(BT), 0, nullptr, n, level, it[cur], sg[cur], d_nodes, d_boxes, d_slots);
+      LAUNCH(k_sah_pick, dim3(gb), dim3(256), 0, nullptr, n0, n1, level, d_nodes, d_slots);
+    }
     LAUNCH(k_scan_local, dim3(nb), dim3(BT), 0, nullptr, n, level, it[cur], sg[cur], d_nodes, d_local, d_tot);
     LAUNCH(k_scan_tops, dim3(1), dim3(BT), 0, nullptr, nb, d_tot);
     LAUNCH(k_children, dim3(gb), dim3(256), 0, nullptr, n0, n1, level, n, nb, d_nodes, d_local, d_tot, d_cnt, d_cnt + 1);

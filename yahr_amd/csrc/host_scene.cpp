@@ -420,15 +420,15 @@ void HostScene::build() {
   lap("boxes");
   nodes.clear();
   std::vector<int32_t> leaf_order;                                    // leaf position -> primitive (expand order)
-  // Which builder?  The GPU one (bvh_build.hip) yields the identical node array and leaf order for the midpoint split
-  // of finite boxes; AUTO takes it for big scenes when a device is there (YAHR_BVH_BUILDER=host|device|auto overrides).
+  // Which builder?  The GPU one (bvh_build.hip) yields the identical node array and leaf order (both split modes) for
+  // finite boxes; AUTO takes it for big scenes when a device is there (YAHR_BVH_BUILDER=host|device|auto overrides).
   int want = builder;
   if (const char *e = std::getenv("YAHR_BVH_BUILDER")) want = !std::strcmp(e, "host") ? YAHR_BUILDER_HOST : !std::strcmp(e, "device") ? YAHR_BUILDER_DEVICE : YAHR_BUILDER_AUTO;
   builder_used = YAHR_BUILDER_HOST; builder_device_ms = 0; builder_note.clear();
   if (want != YAHR_BUILDER_HOST) {
     std::string why;
-    bool ok = split == YAHR_SPLIT_MIDPOINT && prims.size() >= 2 && bvh_depth >= 1 && prims.size() < (size_t)1 << 30;
-    if (!ok) why = "the device builder does the midpoint split of at least two primitives";
+    bool ok = prims.size() >= 2 && bvh_depth >= 1 && prims.size() < (size_t)1 << 30;
+    if (!ok) why = "the device builder splits at least two primitives";
     if (ok && want == YAHR_BUILDER_AUTO && prims.size() < 32768) { ok = false; why = "small scene"; }
     if (ok) {
       std::atomic<bool> bad{false};
@@ -439,7 +439,7 @@ void HostScene::build() {
       });
       if (bad.load()) { ok = false; why = "a primitive's box is not finite"; }
     }
-    if (ok) ok = device_build_bvh(&boxes[0].lo.x, (int32_t)boxes.size(), bvh_depth, nodes, leaf_order, &builder_device_ms, &why);
+    if (ok) ok = device_build_bvh(&boxes[0].lo.x, (int32_t)boxes.size(), bvh_depth, split, nodes, leaf_order, &builder_device_ms, &why);
     if (ok) builder_used = YAHR_BUILDER_DEVICE;
     else {
       builder_note = why;

@@ -89,7 +89,7 @@ void camera_matrices(const Camera &c, float tf[16], float vtf[16]);
 
 // bvh_build.hip: the midpoint BVH built on the GPU with the identical result (node array and leaf order); false = not
 // possible here (no device, out of memory, ...), nothing written
-bool device_build_bvh(const float *boxes, int32_t n, int max_depth, std::vector<yahr_node> &nodes, std::vector<int32_t> &order,
+bool device_build_bvh(const float *boxes, int32_t n, int max_depth, int split, std::vector<yahr_node> &nodes, std::vector<int32_t> &order,
                       double *device_ms, std::string *why);
 
 void set_error(const std::string &msg);

@@ -640,6 +640,8 @@ YD int packet_step(const DScene &sc, const NodeRec &cur, NodeRec &nxt, int i, V3
 //     6 v_sub, 6 v_mul, v_max (0), v_min (tMax'), v_max3, v_min3, v_cmp_ngt -> vcc = the lanes that enter the box
 //     leaf:      vcc != 0 -> leave (index, count, first primitive, mask);  else on to i + 1
 //     interior:  wake = hit ? wake : max(wake, skip);  vcc != 0 -> i + 1 (already requested);  else request `skip`
+// -- on the way from a node to its successor: s_waitcnt, s_add, s_lshl, s_load, s_cmp, two conditional branches that fall
+// through (and one s_branch every second step).
 // Two record buffers, the body written twice with their roles swapped (like packet_loop).  No bounds checks: the node
 // array ends in one zeroed padding record, which reads as a leaf without primitives -- walking onto it (i = n) either
 // leaves the run with i = n or steps to n + 1 = skip-free end, so the run ALSO stops at any index >= n (checked on every
@@ -652,13 +654,16 @@ YD int packet_step(const DScene &sc, const NodeRec &cur, NodeRec &nxt, int i, V3
 // statement drains its last request before it ends, so nothing lands in a register the compiler has taken back.
 // tMax' needs no canonicalisation here: traverse_packet hands over a canonical tMax (a quiet NaN stays "no limit":
 // v_min_f32 returns the other operand).
-#define YD_OCT_BODY(L, NX, FX, NY, FY, NZ, FZ, RA, RB, NXT, CURLO, OTHER)                                   \
+// IDX = the register that holds the index of the node in this body, NXI = the one that receives IDX + 1: body A walks
+// node %[i] and puts i + 1 into %[nx], body B walks node %[nx] and puts nx + 1 into %[i] -- no register move on the way
+// from a node to its successor, and body A FALLS THROUGH into body B.  On every exit the index of the last node is in %[i].
+#define YD_OCT_STEP(L, IDX, NXI, NX, FX, NY, FY, NZ, FZ, RA, RB, NXT)                                       \
   ".Loct%=_" L ":\n\t"                                                                                       \
   "s_waitcnt lgkmcnt(0)\n\t"                                                                                 \
-  "s_add_i32 %[nx], %[i], 1\n\t"                                                                             \
-  "s_lshl_b32 %[off], %[nx], 5\n\t"                                                                          \
+  "s_add_i32 " NXI ", " IDX ", 1\n\t"                                                                        \
+  "s_lshl_b32 %[off], " NXI ", 5\n\t"                                                                        \
   "s_load_dwordx8 " NXT ", %[base], %[off]\n\t"                                                              \
-  "v_cmp_ge_i32_e32 vcc, %[i], %[wake]\n\t"                                                                  \
+  "v_cmp_ge_i32_e32 vcc, " IDX ", %[wake]\n\t"                                                               \
   "v_sub_f32_e32 %[t0], " NX ", %[ox]\n\t"                                                                   \
   "v_sub_f32_e32 %[t2], " NY ", %[oy]\n\t"                                                                   \
   "v_sub_f32_e32 %[t4], " NZ ", %[oz]\n\t"                                                                   \
@@ -681,10 +686,10 @@ YD int packet_step(const DScene &sc, const NodeRec &cur, NodeRec &nxt, int i, V3
   "s_cbranch_scc0 .Loct%=_" L "_leaf\n\t"                                                                    \
   "v_max_i32_e32 %[t2], " RA ", %[wake]\n\t"                                                                 \
   "v_cndmask_b32_e32 %[wake], %[t2], %[wake], vcc\n\t"                                                       \
-  "s_cbranch_vccz .Loct%=_" L "_skip\n\t"                                                                    \
-  "s_mov_b32 %[i], %[nx]\n\t"                                                                                \
-  "s_branch .Loct%=_" OTHER "\n"                                                                             \
-  ".Loct%=_" L "_skip:\n\t"                                                                                  \
+  "s_cbranch_vccz .Loct%=_" L "_skip\n\t"
+// the rarer ways out of a step, placed behind the two bodies
+#define YD_OCT_TAIL(L, IDX, NXI, RA, RB, OTHER)                                                              \
+  ".Loct%=_" L "_skip:\n\t"                        /* no lane entered the interior node: on to its skip target */  \
   "s_mov_b32 %[i], " RA "\n\t"                                                                               \
   "s_cmp_ge_i32 %[i], %[n]\n\t"                                                                              \
   "s_cbranch_scc1 .Loct%=_end\n\t"                                                                           \
@@ -693,22 +698,26 @@ YD int packet_step(const DScene &sc, const NodeRec &cur, NodeRec &nxt, int i, V3
   "s_load_dwordx8 s[48:55], %[base], %[off]\n\t"                                                             \
   "s_branch .Loct%=_A\n"                                                                                     \
   ".Loct%=_" L "_leaf:\n\t"                                                                                  \
-  "s_cbranch_vccnz .Loct%=_" L "_hit\n\t"                                                                    \
-  "s_mov_b32 %[i], %[nx]\n\t"                                                                                \
-  "s_cmp_ge_i32 %[i], %[n]\n\t"                                                                              \
-  "s_cbranch_scc1 .Loct%=_end\n\t"                                                                           \
-  "s_branch .Loct%=_" OTHER "\n"                                                                             \
+  "s_cbranch_vccnz .Loct%=_" L "_hit\n\t"          /* a leaf no lane entered: on to the next node */             \
+  "s_cmp_ge_i32 " NXI ", %[n]\n\t"                                                                           \
+  "s_cbranch_scc0 .Loct%=_" OTHER "\n\t"                                                                     \
+  "s_mov_b32 %[i], " NXI "\n\t"                                                                              \
+  "s_branch .Loct%=_end\n"                                                                                   \
   ".Loct%=_" L "_hit:\n\t"                                                                                   \
   "s_mov_b32 %[la], " RA "\n\t"                                                                              \
   "s_mov_b32 %[lb], " RB "\n\t"                                                                              \
   "s_mov_b64 %[hm], vcc\n\t"                                                                                 \
+  "s_mov_b32 %[i], " IDX "\n\t"                                                                              \
   "s_branch .Loct%=_end\n"
 // record in s[48:55] / s[56:63]:  lo.x lo.y lo.z a hi.x hi.y hi.z b
 #define YD_OCT_RUN(NXA, FXA, NYA, FYA, NZA, FZA, NXB, FXB, NYB, FYB, NZB, FZB)                                \
   asm("s_mov_b32 s48, %[r0]\n\ts_mov_b32 s49, %[r1]\n\ts_mov_b32 s50, %[r2]\n\ts_mov_b32 s51, %[r3]\n\t"     \
       "s_mov_b32 s52, %[r4]\n\ts_mov_b32 s53, %[r5]\n\ts_mov_b32 s54, %[r6]\n\ts_mov_b32 s55, %[r7]\n"       \
-      YD_OCT_BODY("A", NXA, FXA, NYA, FYA, NZA, FZA, "s51", "s55", "s[56:63]", "s48", "B")                   \
-      YD_OCT_BODY("B", NXB, FXB, NYB, FYB, NZB, FZB, "s59", "s63", "s[48:55]", "s56", "A")                   \
+      YD_OCT_STEP("A", "%[i]", "%[nx]", NXA, FXA, NYA, FYA, NZA, FZA, "s51", "s55", "s[56:63]")              \
+      YD_OCT_STEP("B", "%[nx]", "%[i]", NXB, FXB, NYB, FYB, NZB, FZB, "s59", "s63", "s[48:55]")              \
+      "s_branch .Loct%=_A\n"                                                                                 \
+      YD_OCT_TAIL("A", "%[i]", "%[nx]", "s51", "s55", "B")                                                   \
+      YD_OCT_TAIL("B", "%[nx]", "%[i]", "s59", "s63", "A")                                                   \
       ".Loct%=_end:\n\t"                                                                                     \
       "s_waitcnt lgkmcnt(0)\n"                                                                               \
       : [i] "+s"(i), [wake] "+v"(wake), [la] "+s"(la), [lb] "+s"(lb), [hm] "+s"(hm), [nx] "=&s"(nx), [off] "=&s"(off),     \
@@ -749,6 +758,12 @@ YD int packet_loop_oct(const DScene &sc, int oct, bool active, V3 o, V3 u, V3 in
   wake = active ? 0 : YD_DONE;
   const int cull_min = (sc.boxes_finite & 2) ? YD_CULL_MIN : 0x7fffffff;   // wave-uniform (leaf_culled)
   int i = 0;
+#ifdef YD_PRIO_VISITS
+  int visits = 0;
+#ifndef YD_PRIO_LEVEL
+#define YD_PRIO_LEVEL 3
+#endif
+#endif
   NodeRec A = load_node(sc, 0);
   for (;;) {
     int a = 0, b = 0;
@@ -769,7 +784,12 @@ YD int packet_loop_oct(const DScene &sc, int oct, bool active, V3 o, V3 u, V3 in
     a = __builtin_amdgcn_readfirstlane(a);
     b = __builtin_amdgcn_readfirstlane(b);
     hm = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(hm >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)hm);
-    if (i >= n) return n;
+    if (i >= n) break;
+#ifdef YD_PRIO_VISITS
+    // a traversal that has visited many leaves belongs to one of the few long wavefronts that decide when a LONE frame is
+    // done; while the chip is full they crawl at a seventh of a SIMD -- let them issue ahead of their neighbours
+    if (++visits == YD_PRIO_VISITS) __builtin_amdgcn_s_setprio(YD_PRIO_LEVEL);
+#endif
     A = load_node(sc, i + 1);                                             // the node after the leaf, requested ahead of its primitives
     const PrimRec p0 = load_prim(sc, b);
     const bool h = __builtin_amdgcn_inverse_ballot_w64(hm);
@@ -779,13 +799,17 @@ YD int packet_loop_oct(const DScene &sc, int oct, bool active, V3 o, V3 u, V3 in
       if (got) wake = YD_DONE;
       if (wany(got)) {
         const int m = __builtin_amdgcn_readfirstlane(wave_min_i32(wake));
-        if (m == YD_DONE) return n;
+        if (m == YD_DONE) break;
         if (m > next) { next = m; A = load_node(sc, next); }
       }
     }
-    if (next >= n) return n;
+    if (next >= n) break;
     i = next;
   }
+#ifdef YD_PRIO_VISITS
+  if (visits >= YD_PRIO_VISITS) __builtin_amdgcn_s_setprio(0);
+#endif
+  return n;
 }
 
 // The loop body exists twice with the two node buffers swapped: a step to the next node in array order (every
@@ -977,7 +1001,8 @@ YD void traverse_block(const DScene &sc, bool active, bool any_hit, bool coheren
 }
 
 // ---- shading --------------------------------------------------------------------------------------
-// DifferentialGeometry of the accepted hit (Shapes.hs:23-28, 49-55); returns the material index
+// DifferentialGeometry of the accepted hit (Shapes.hs:23-28, 49-55); returns the material index.  `dpdu` comes back
+// NORMALISED (see the end of the function).
 YD int surface_of(const DScene &sc, V3 ro, V3 rd, const Hit &hit, V3 &x, V3 &n, V3 &dpdu) {
   const PrimRec p = load_prim(sc, hit.prim);
   x = ro + scale(hit.t, rd);                                          // dgPoint / rayAt
@@ -993,10 +1018,14 @@ YD int surface_of(const DScene &sc, V3 ro, V3 rd, const Hit &hit, V3 &x, V3 &n, 
     n = nn;
     dpdu = cross(nn, v3(0.0f, 0.0f, 1.0f));
   }
+  // What travels on from here is sn = norm dgDPDU, the only thing the BSDF frame takes from dpdu (BSDF.hs:36-38): every
+  // BSDF.at of this hit -- one per light and one for the reflection -- would form it again from the same three floats.
+  dpdu = norm(dpdu);
   return __float_as_int(p.r0.w);
 }
 
-// BSDF.at (blinnPhong material) dg wi wo   (Shaders.hs:12-14, BSDF.hs:12-46); mat < 0: unknown material
+// BSDF.at (blinnPhong material) dg wi wo   (Shaders.hs:12-14, BSDF.hs:12-46); mat < 0: unknown material.
+// dpdu = norm dgDPDU, as surface_of hands it out
 YD V3 material_at(const DScene &sc, int mat, V3 n, V3 dpdu, V3 wi, V3 wo) {
   V3 diffuse = vof(0.0f), specular = vof(0.0f); float shininess = 0.0f;
   if (mat >= 0) {
@@ -1004,7 +1033,7 @@ YD V3 material_at(const DScene &sc, int mat, V3 n, V3 dpdu, V3 wi, V3 wo) {
     const float4 m0 = mats[2 * (size_t)mat], m1 = mats[2 * (size_t)mat + 1];
     diffuse = xyz(m0); shininess = m0.w; specular = xyz(m1);
   }
-  const Frame fr = bsdf_frame(n, dpdu);
+  Frame fr; fr.nn = n; fr.sn = dpdu; fr.tn = cross(fr.nn, fr.sn);      // bsdf_frame with sn = norm dpdu already formed (surface_of)
   return blinn_phong_at(diffuse, specular, shininess, fr, wi, wo);
 }
 
@@ -1304,6 +1333,9 @@ void k_render(DScene sc_in, YD_SCENE_PARAMS, RParams rp, float *__restrict__ out
   Counters c = {};
   bool bad_mat = false;
   const unsigned long long t_start = STATS ? clock64() : 0ULL;
+#ifdef YD_TILE_CLOCK
+  const unsigned long long t_clock0 = wall_clock64();
+#endif
   // NOTE: the ONLY global stores of this kernel come after the last traversal.  A store (or atomic) ahead of
   // a scene load makes that load "clobberable" for the compiler, which then refuses the scalar-load path and
   // silently turns the packet walker's node fetches into per-lane gathers (tests/test_isa.py guards this).
@@ -1351,6 +1383,14 @@ void k_render(DScene sc_in, YD_SCENE_PARAMS, RParams rp, float *__restrict__ out
   out += (size_t)frame * rp.frame_stride;
   if (rp.sil_log2 != 0) valid = valid && j0 == 0;      // the pixel's first lane stores it
   if (rp.spp > 1) acc = scale(1.0f / (float)rp.spp, acc);
+#ifdef YD_TILE_CLOCK
+  // diagnostics build (tools/tile_clock.py): lane 0 of every wavefront reports when it ran instead of its pixel --
+  // duration and start in ticks of the constant 100 MHz clock, and the hardware id of the wave slot
+  if (lane == 0) {
+    const unsigned long long t1 = wall_clock64();
+    acc = v3((float)(t1 - t_clock0), (float)(t_clock0 & 0xffffffULL), (float)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)));
+  }
+#endif
   if (valid) {
     float *px = out + (row * rp.width + u) * 3;          // samplesToImage: w*v+u (main.hs:100)
     px[0] = acc.x; px[1] = acc.y; px[2] = acc.z;

@@ -23,13 +23,16 @@
 // bit for bit; shadow rays stop at the first accepted primitive (same Bool as Rays.hs:49-54).
 //
 // Kernels: k_render<MODE, STATS, WPB, DEEP> (fused: one wavefront renders its tile's pixels to the end; DEEP = recursion
-// depth > 3, upper levels of the radiance stack in global memory), and the wavefront ("stream") form k_stream_primary /
+// depth > 2, upper levels of the radiance stack in global memory), and the wavefront ("stream") form k_stream_primary /
 // k_stream_level / k_stream_resolve with the counting sort k_sort_* in between (paths compacted between bounces).
 //
 // What bounds the fused kernel (rocprofv3 PMC, profiles/): not bytes -- the whole scene sits in L2/MALL and a
-// frame moves ~33 MB over HBM, 25 of them the image -- but vector-instruction issue and, for a lone frame, the serial
-// chains of the heaviest wavefronts: a wave issues one instruction per ~4 clocks, and a tile over dense geometry walks
-// thousands of dependent node/primitive steps.  So the code is shaped for FEW INSTRUCTIONS PER STEP:
+// frame moves ~43 MB over HBM, 25 of them the image -- but vector-instruction issue and, for a lone frame, the serial
+// chains of the heaviest wavefronts: a tile over dense geometry walks thousands of dependent node/primitive steps, each
+// of which waits for a scalar-load round trip.  So the code is shaped for FEW INSTRUCTIONS PER STEP:
+//   * packets whose rays share a direction octant walk from node to node in hand-written assembly (oct_run: 21 VALU per
+//     step instead of 29), fat multiLeafs are settled per packet (leaf_culled), and the state of the radiance recursion
+//     waits in LDS, not in registers, across the traversals (radiance) -- round 4;
 //   * each walker is instantiated once per kernel (radiance is a wave-uniform state machine with a single
 //     traversal call site; first-hit mode is a run-time flag; one pixel loop for all tilings / sample counts);
 //   * the fast build carries no counters at all (ray and test counts come from the collect_stats build);

@@ -1468,7 +1468,7 @@ def test_device_bvh_build_sah_is_the_host_tree(gpu, case, tris1m):
     print(f"SAH {case}: {dev.flat.contents.n_prims} primitives, {dev.flat.contents.n_nodes} nodes, device build {ms:.2f} ms")
     assert _same_flat_scene(host.arrays(), dev.arrays()) is None
     if case == "tris1m_d20":
-        assert ms <= 10.0, ms
+        assert ms <= 25.0, ms                  # (measured 8.7 ms; the bound only guards against a fall back to something slow)
 
 
 def test_device_bvh_build_sah_fuzz(gpu):

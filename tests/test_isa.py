@@ -74,12 +74,13 @@ def test_packet_walker_uses_scalar_loads(asm):
     assert "s_barrier" in kernel_body(asm, PACKET_REGROUP)
 
 
-def test_octant_run_is_21_valu_per_node_step(asm):
+def test_octant_run_is_17_valu_per_node_step(asm):
     """oct_run (render_kernel.hip): the hand-written walk from node to node for packets that share a direction octant.
-    Per step: the request for node i + 1 goes out BEFORE the slab arithmetic; 19 VALU up to the leaf / interior branch
-    (on, tMax', six subtractions, six multiplications, max with 0, min with tMax', v_max3, v_min3, the compare into vcc)
-    and two more on the interior path (the sleep update) -- 21 against the 29 of the generic loop; no per-axis
-    v_min / v_max pairs; eight octants x two loops (closest hit, first hit), each body twice (record buffers swapped)."""
+    Per step: the request for node i + 1 goes out BEFORE the slab arithmetic; 17 VALU (six subtractions, six
+    multiplications, max with 0, min with tMax, v_max3, v_min3, the compare into vcc) against the 29 of the generic
+    loop: no per-axis v_min / v_max pairs and -- the tree's boxes are nested -- no per-lane memory of the subtrees a lane
+    has left (no v_cndmask, no integer VALU); eight octants x two loops (closest hit, first hit), each body twice (record
+    buffers swapped)."""
     body = kernel_body(asm, PACKET_FAST)
     runs = re.findall(r"^\.Loct(\d+)_A:\n(.*?)^\.Loct\1_end:", body, flags=re.S | re.M)
     assert len(runs) == 16, len(runs)
@@ -88,11 +89,11 @@ def test_octant_run_is_21_valu_per_node_step(asm):
         first_branch = next(i for i, l in enumerate(lines) if l.startswith("s_cbranch"))
         head = lines[:first_branch]
         assert head[0].startswith("s_waitcnt lgkmcnt(0)") and any(l.startswith("s_load_dwordx8") for l in head[:5]), head[:5]
-        assert sum(l.startswith("v_") for l in head) == 19, head
-        tail = lines[first_branch + 1:first_branch + 4]
-        assert tail[0].startswith("v_max_i32") and tail[1].startswith("v_cndmask") and tail[2].startswith("s_cbranch_vccz"), tail
+        assert sum(l.startswith("v_") for l in head) == 17, head
+        assert lines[first_branch + 1].startswith("s_cbranch_vccz"), lines[first_branch:first_branch + 2]
+        assert not re.search(r"v_cndmask|v_max_i32|v_cmp_ge_i32", text)
         assert len(re.findall(r"v_max3_f32", text)) == 2 and len(re.findall(r"v_min3_f32", text)) == 2       # bodies A and B
-        assert len(re.findall(r"v_(min|max)_f32_e32", text)) == 4                                                # max(., 0), min(., tMax')
+        assert len(re.findall(r"v_(min|max)_f32_e32", text)) == 4                                                # max(., 0), min(., tMax)
     # the counting build keeps the generic loop (its counters are per step); the camera-ray launch of the wavefront form
     # has the run, and so have its level launches for their shadow rays (first hit only: eight copies)
     assert ".Loct" not in kernel_body(asm, PACKET_STATS)

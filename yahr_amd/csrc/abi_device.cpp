@@ -395,6 +395,23 @@ static int ctx_create_impl(const yahr_scene *s, int device, yahr_ctx **out, size
     for (int k = 0; k < 3; ++k)
       if (!std::isfinite(s->nodes[i].lo[k]) || !std::isfinite(s->nodes[i].hi[k]) || !(s->nodes[i].lo[k] <= s->nodes[i].hi[k]))
         d.boxes_finite = 0;
+  // bit 2: every child's box lies inside its parent's (it does in every tree Culling.hs:39 or this library builds -- a
+  // parent's box IS the join of its children's -- but the node array is the caller's).  The octant run of the packet walker
+  // relies on it: a ray that failed a node's box then fails every box below it (render_kernel.hip), so lanes need no
+  // memory of the subtrees they left.  YAHR_NO_NESTED=1 clears the bit (A/B measurements, tests).
+  if (d.boxes_finite && !(std::getenv("YAHR_NO_NESTED") && std::atoi(std::getenv("YAHR_NO_NESTED")) != 0)) {
+    bool nested = true;
+    for (int32_t i = 0; i + 2 < s->n_nodes && nested; ++i) {
+      const yahr_node &p = s->nodes[i];
+      if (p.b != -1) continue;                                            // leaf
+      const int32_t l = i + 1, r = s->nodes[l].b == -1 ? s->nodes[l].a : l + 1;
+      if (r <= l || r >= s->n_nodes) { nested = false; break; }
+      for (int k = 0; k < 3; ++k)
+        if (!(s->nodes[l].lo[k] >= p.lo[k] && s->nodes[l].hi[k] <= p.hi[k] && s->nodes[r].lo[k] >= p.lo[k] && s->nodes[r].hi[k] <= p.hi[k]))
+          nested = false;
+    }
+    if (nested) d.boxes_finite |= 4;
+  }
   // bit 1: every triangle record small enough for the packet-level tri_far proof (device_math.hpp: tri_far_packet;
   // YAHR_NO_LEAF_CULL=1 switches the fat-leaf culling of the packet walker off: A/B measurements)
   {

@@ -666,11 +666,9 @@ YD int packet_step(const DScene &sc, const NodeRec &cur, NodeRec &nxt, int i, V3
   "s_add_i32 " NXI ", " IDX ", 1\n\t"                                                                        \
   "s_lshl_b32 %[off], " NXI ", 5\n\t"                                                                        \
   "s_load_dwordx8 " NXT ", %[base], %[off]\n\t"                                                              \
-  "v_cmp_ge_i32_e32 vcc, " IDX ", %[wake]\n\t"                                                               \
   "v_sub_f32_e32 %[t0], " NX ", %[ox]\n\t"                                                                   \
   "v_sub_f32_e32 %[t2], " NY ", %[oy]\n\t"                                                                   \
   "v_sub_f32_e32 %[t4], " NZ ", %[oz]\n\t"                                                                   \
-  "v_cndmask_b32_e32 %[t3], -1.0, %[tmax], vcc\n\t"                                                          \
   "v_sub_f32_e32 %[t1], " FX ", %[ox]\n\t"                                                                   \
   "v_mul_f32_e32 %[t0], %[t0], %[ix]\n\t"                                                                    \
   "v_mul_f32_e32 %[t2], %[t2], %[iy]\n\t"                                                                    \
@@ -682,13 +680,11 @@ YD int packet_step(const DScene &sc, const NodeRec &cur, NodeRec &nxt, int i, V3
   "v_sub_f32_e32 %[t4], " FZ ", %[oz]\n\t"                                                                   \
   "v_mul_f32_e32 %[t2], %[t2], %[iy]\n\t"                                                                    \
   "v_mul_f32_e32 %[t4], %[t4], %[iz]\n\t"                                                                    \
-  "v_min_f32_e32 %[t4], %[t4], %[t3]\n\t"                                                                    \
+  "v_min_f32_e32 %[t4], %[t4], %[tmax]\n\t"                                                                  \
   "v_min3_f32 %[t1], %[t1], %[t2], %[t4]\n\t"                                                                \
   "v_cmp_ngt_f32_e32 vcc, %[t0], %[t1]\n\t"                                                                  \
   "s_cmp_lt_i32 " RB ", 0\n\t"                                                                               \
   "s_cbranch_scc0 .Loct%=_" L "_leaf\n\t"                                                                    \
-  "v_max_i32_e32 %[t2], " RA ", %[wake]\n\t"                                                                 \
-  "v_cndmask_b32_e32 %[wake], %[t2], %[wake], vcc\n\t"                                                       \
   "s_cbranch_vccz .Loct%=_" L "_skip\n\t"
 // the rarer ways out of a step, placed behind the two bodies
 #define YD_OCT_TAIL(L, IDX, NXI, RA, RB, OTHER)                                                              \
@@ -723,8 +719,8 @@ YD int packet_step(const DScene &sc, const NodeRec &cur, NodeRec &nxt, int i, V3
       YD_OCT_TAIL("B", "%[nx]", "%[i]", "s59", "s63", "A")                                                   \
       ".Loct%=_end:\n\t"                                                                                     \
       "s_waitcnt lgkmcnt(0)\n"                                                                               \
-      : [i] "+s"(i), [wake] "+v"(wake), [la] "+s"(la), [lb] "+s"(lb), [hm] "+s"(hm), [nx] "=&s"(nx), [off] "=&s"(off),     \
-        [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4)                                    \
+      : [i] "+s"(i), [la] "+s"(la), [lb] "+s"(lb), [hm] "+s"(hm), [nx] "=&s"(nx), [off] "=&s"(off),                        \
+        [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t4] "=&v"(t4)                                                    \
       : [base] "s"(base), [n] "s"(n), [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z), [ix] "v"(inv.x), [iy] "v"(inv.y),      \
         [iz] "v"(inv.z), [tmax] "v"(tmax), [r0] "s"(A.lo.x), [r1] "s"(A.lo.y), [r2] "s"(A.lo.z), [r3] "s"(A.lo.w),        \
         [r4] "s"(A.hi.x), [r5] "s"(A.hi.y), [r6] "s"(A.hi.z), [r7] "s"(A.hi.w)                                            \
@@ -736,10 +732,10 @@ YD int packet_step(const DScene &sc, const NodeRec &cur, NodeRec &nxt, int i, V3
 // tMax cannot change in here (no primitive is tested), wake does.  OCT bit k set: inv component k is negative, the hi
 // plane of that axis is the near one.
 template <int OCT>
-YD int oct_run(const float4 *base, int n, int i, const NodeRec &A, V3 o, V3 inv, float tmax, int &wake, int &la, int &lb,
+YD int oct_run(const float4 *base, int n, int i, const NodeRec &A, V3 o, V3 inv, float tmax, int &la, int &lb,
                unsigned long long &hm) {
   int nx, off;
-  float t0, t1, t2, t3, t4;
+  float t0, t1, t2, t4;
 #define YD_N(bit, lo, hi) ((OCT & bit) ? hi : lo)
   // (the operand names must be string literals: one statement per octant)
   if (OCT == 0) YD_OCT_RUN("s48", "s52", "s49", "s53", "s50", "s54", "s56", "s60", "s57", "s61", "s58", "s62");
@@ -751,14 +747,21 @@ YD int oct_run(const float4 *base, int n, int i, const NodeRec &A, V3 o, V3 inv,
   if (OCT == 6) YD_OCT_RUN("s48", "s52", "s53", "s49", "s54", "s50", "s56", "s60", "s61", "s57", "s62", "s58");
   if (OCT == 7) YD_OCT_RUN("s52", "s48", "s53", "s49", "s54", "s50", "s60", "s56", "s61", "s57", "s62", "s58");
 #undef YD_N
-  return i;
+  // (asm outputs: tell the compiler they are wave-uniform -- it takes them for per-lane values otherwise and builds the
+  // whole leaf code with exec-masked loops and per-lane gathers of the primitive records.  Here, next to the statement,
+  // a readfirstlane of a scalar register folds away; behind the switch over the octants it cost ten VALU per leaf visit)
+  la = __builtin_amdgcn_readfirstlane(la);
+  lb = __builtin_amdgcn_readfirstlane(lb);
+  hm = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(hm >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)hm);
+  return __builtin_amdgcn_readfirstlane(i);
 }
 
 template <bool ANY, bool CULL>
-YD int packet_loop_oct(const DScene &sc, int oct, bool active, V3 o, V3 u, V3 inv, float &tmax, Hit &hit, int &wake, Counters &c) {
+YD int packet_loop_oct(const DScene &sc, int oct, bool active, V3 o, V3 u, V3 inv, float &tmax, Hit &hit, Counters &c) {
   constexpr bool any_hit = ANY;
   const int n = sc.n_nodes;
-  wake = active ? 0 : YD_DONE;
+  // a lane that takes no part (any more) misses every box: tFar = min(.., -1) < 0 <= tNear
+  if (!active) tmax = -1.0f;
   const int cull_min = (sc.boxes_finite & 2) ? YD_CULL_MIN : 0x7fffffff;   // wave-uniform (leaf_culled)
   int i = 0;
 #ifdef YD_PRIO_VISITS
@@ -772,21 +775,15 @@ YD int packet_loop_oct(const DScene &sc, int oct, bool active, V3 o, V3 u, V3 in
     int a = 0, b = 0;
     unsigned long long hm = 0ULL;
     switch (oct) {                                                        // wave-uniform: one copy of the run per octant
-      case 0: i = oct_run<0>(sc.nodes, n, i, A, o, inv, tmax, wake, a, b, hm); break;
-      case 1: i = oct_run<1>(sc.nodes, n, i, A, o, inv, tmax, wake, a, b, hm); break;
-      case 2: i = oct_run<2>(sc.nodes, n, i, A, o, inv, tmax, wake, a, b, hm); break;
-      case 3: i = oct_run<3>(sc.nodes, n, i, A, o, inv, tmax, wake, a, b, hm); break;
-      case 4: i = oct_run<4>(sc.nodes, n, i, A, o, inv, tmax, wake, a, b, hm); break;
-      case 5: i = oct_run<5>(sc.nodes, n, i, A, o, inv, tmax, wake, a, b, hm); break;
-      case 6: i = oct_run<6>(sc.nodes, n, i, A, o, inv, tmax, wake, a, b, hm); break;
-      default: i = oct_run<7>(sc.nodes, n, i, A, o, inv, tmax, wake, a, b, hm); break;
+      case 0: i = oct_run<0>(sc.nodes, n, i, A, o, inv, tmax, a, b, hm); break;
+      case 1: i = oct_run<1>(sc.nodes, n, i, A, o, inv, tmax, a, b, hm); break;
+      case 2: i = oct_run<2>(sc.nodes, n, i, A, o, inv, tmax, a, b, hm); break;
+      case 3: i = oct_run<3>(sc.nodes, n, i, A, o, inv, tmax, a, b, hm); break;
+      case 4: i = oct_run<4>(sc.nodes, n, i, A, o, inv, tmax, a, b, hm); break;
+      case 5: i = oct_run<5>(sc.nodes, n, i, A, o, inv, tmax, a, b, hm); break;
+      case 6: i = oct_run<6>(sc.nodes, n, i, A, o, inv, tmax, a, b, hm); break;
+      default: i = oct_run<7>(sc.nodes, n, i, A, o, inv, tmax, a, b, hm); break;
     }
-    // (asm outputs: tell the compiler they are wave-uniform -- it takes them for per-lane values otherwise and builds the
-    // whole leaf code below with exec-masked loops and per-lane gathers of the primitive records)
-    i = __builtin_amdgcn_readfirstlane(i);
-    a = __builtin_amdgcn_readfirstlane(a);
-    b = __builtin_amdgcn_readfirstlane(b);
-    hm = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(hm >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)hm);
     if (i >= n) break;
 #ifdef YD_PRIO_VISITS
     // a traversal that has visited many leaves belongs to one of the few long wavefronts that decide when a LONE frame is
@@ -797,17 +794,14 @@ YD int packet_loop_oct(const DScene &sc, int oct, bool active, V3 o, V3 u, V3 in
     const PrimRec p0 = load_prim(sc, b);
     const bool h = __builtin_amdgcn_inverse_ballot_w64(hm);
     const bool got = packet_leaf<false, true, ANY, CULL>(sc, a, b, p0, h, o, u, tmax, hit, c, cull_min);
-    int next = i + 1;
     if (any_hit) {
-      if (got) wake = YD_DONE;
-      if (wany(got)) {
-        const int m = __builtin_amdgcn_readfirstlane(wave_min_i32(wake));
-        if (m == YD_DONE) break;
-        if (m > next) { next = m; A = load_node(sc, next); }
-      }
+      // a lane with its first hit is finished; the walk goes on from i + 1 for the others (no jump to the next node some
+      // lane still needs, as packet_loop makes: the nodes in between fail for every lane and leave by their skip links)
+      if (got) tmax = -1.0f;
+      if (wany(got) && !wany(!(tmax < 0.0f))) break;                      // (a lane whose tMax was negative from the start cannot hit anything)
     }
-    if (next >= n) break;
-    i = next;
+    if (i + 1 >= n) break;
+    i = i + 1;
   }
 #ifdef YD_PRIO_VISITS
   if (visits >= YD_PRIO_VISITS) __builtin_amdgcn_s_setprio(0);
@@ -875,7 +869,7 @@ YD void traverse_packet(const DScene &sc, bool active, bool any_hit, V3 o, V3 u,
 #ifndef YD_OCT_MIN_NODES
 #define YD_OCT_MIN_NODES 64
 #endif
-  if (OCT && !STATS && !ADAPT && fast && n >= YD_OCT_MIN_NODES) {
+  if (OCT && !STATS && !ADAPT && fast && (sc.boxes_finite & 4) && n >= YD_OCT_MIN_NODES) {
     const unsigned long long act = __builtin_amdgcn_ballot_w64(active);
     const unsigned long long mx = __builtin_amdgcn_ballot_w64(active & (inv.x < 0.0f)), my = __builtin_amdgcn_ballot_w64(active & (inv.y < 0.0f)),
                              mz = __builtin_amdgcn_ballot_w64(active & (inv.z < 0.0f));
@@ -884,8 +878,8 @@ YD void traverse_packet(const DScene &sc, bool active, bool any_hit, V3 o, V3 u,
   }
 #endif
   if (OCT && !STATS && !ADAPT && fast && oct_ok) {
-    if (any_hit) i = packet_loop_oct<true, CULL>(sc, oct, active, o, u, inv, tmax, hit, wake, c);
-    else i = packet_loop_oct<false, CULL>(sc, oct, active, o, u, inv, tmax, hit, wake, c);
+    if (any_hit) i = packet_loop_oct<true, CULL>(sc, oct, active, o, u, inv, tmax, hit, c);
+    else i = packet_loop_oct<false, CULL>(sc, oct, active, o, u, inv, tmax, hit, c);
   } else if (fast) {
     if (any_hit) i = packet_loop<STATS, true, ADAPT, true, CULL>(sc, active, o, u, inv, tmax, hit, wake, c);
     else i = packet_loop<STATS, true, ADAPT, false, CULL>(sc, active, o, u, inv, tmax, hit, wake, c);

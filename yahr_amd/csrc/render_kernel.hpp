@@ -26,6 +26,7 @@ struct DScene {
   int depth;
   int boxes_finite;        // bit 0: every node box has finite lo <= hi (enables the NaN-free slab form);
                            // bit 1: every triangle record's p0, e1, e2 within +-2^32 (enables tri_far_packet, device_math.hpp)
+                           // bit 2: every child's box inside its parent's (enables the octant run, render_kernel.hip)
 };
 
 // Child-pair records for the stack walkers (render_kernel.hip: stack_loop), handed to the kernels that may run them (kept

@@ -935,6 +935,54 @@ def test_extreme_scene_renders_the_same_in_all_forms(gpu):
                     assert st0[k] == st1[k], (k, bvh_depth, spp, m)
 
 
+def test_octant_run_only_on_nested_boxes(gpu, monkeypatch):
+    """The octant run of the packet walker keeps no per-lane memory of the subtrees a lane has left: a ray that fails a
+    node's box fails every box below it, because a child's box lies inside its parent's (render_kernel.hip: oct_run).  That
+    holds for every tree Culling.hs or this library builds and is CHECKED per scene when a context is created
+    (abi_device.cpp, DScene.boxes_finite bit 2) -- the node array is the caller's.  Here: (a) with the check's result
+    overridden (YAHR_NO_NESTED=1: generic loop with its sleep index) the images are the ones the run gives; (b) a tree
+    whose interior boxes have been SHRUNK under their children (still a legal input: every walker skips what a shrunken
+    box hides) renders the same in every form -- the lane walker, which assumes nothing, included -- and differently from
+    the intact tree, so the comparison does see the boxes; (c) with nestedness CLAIMED for that tree (test hook) the
+    packet walker's image is no longer the lane walker's: the check is what protects the run."""
+    desc = scenes.pseudo_bunny(320, 180)
+    scene = desc.to_scene().build()
+    forms = (yahr_amd.TRAVERSE_LANE, yahr_amd.TRAVERSE_PACKET, yahr_amd.TRAVERSE_HYBRID, yahr_amd.TRAVERSE_STREAM, yahr_amd.TRAVERSE_AUTO)
+    monkeypatch.setenv("YAHR_NO_NESTED", "1")
+    off = yahr_amd.Context(scene, 0)
+    monkeypatch.delenv("YAHR_NO_NESTED")
+    on = yahr_amd.Context(scene, 0)
+    intact = None
+    for spp in (1, 4):
+        for trav in forms:
+            a = off.render(traverse=trav, spp=spp, seed=5).cpu().numpy()
+            b = on.render(traverse=trav, spp=spp, seed=5).cpu().numpy()
+            assert a.any() and np.array_equal(bits(a), bits(b)), (spp, trav)
+            if intact is None:
+                intact = a
+    off.close(); on.close()
+    # (b) shrink every third interior node's box by a quarter of its extent on the high side, in the scene's own arrays
+    f = scene.flat.contents
+    nodes = np.ctypeslib.as_array(ctypes.cast(f.nodes, ctypes.POINTER(ctypes.c_float)), shape=(f.n_nodes, 8))
+    inter = np.flatnonzero(nodes[:, 7].view(np.int32) == -1)[1::3]
+    assert len(inter) > 1000
+    nodes[inter, 4:7] -= np.float32(0.25) * (nodes[inter, 4:7] - nodes[inter, 0:3])
+    ctx = yahr_amd.Context(scene, 0)
+    ref = ctx.render(traverse=yahr_amd.TRAVERSE_LANE, seed=5).cpu().numpy()
+    assert not np.array_equal(bits(ref), bits(intact))
+    for trav in forms[1:]:
+        b = ctx.render(traverse=trav, seed=5).cpu().numpy()
+        assert np.array_equal(bits(ref), bits(b)), trav
+    ctx.close()
+    # (c)
+    monkeypatch.setenv("YAHR_DEBUG_ASSUME_NESTED", "1")
+    ctx = yahr_amd.Context(scene, 0)
+    monkeypatch.delenv("YAHR_DEBUG_ASSUME_NESTED")
+    b = ctx.render(traverse=yahr_amd.TRAVERSE_PACKET, seed=5).cpu().numpy()
+    assert not np.array_equal(bits(ref), bits(b))
+    ctx.close()
+
+
 def test_fat_leaf_culling_changes_nothing(gpu, monkeypatch):
     """The packet walker settles most primitive steps of a fat multiLeaf for the whole packet at once (leaf_culled: the rays'
     box in ray space, tri_stage0 in interval arithmetic, one triangle per lane).  A skipped step is one that would have

@@ -412,6 +412,9 @@ static int ctx_create_impl(const yahr_scene *s, int device, yahr_ctx **out, size
     }
     if (nested) d.boxes_finite |= 4;
   }
+  // (test hook: claim nestedness unchecked -- tests/test_gpu_parity.py shows with it that the check above is what keeps the
+  // octant run off trees it would walk wrongly)
+  if (d.boxes_finite && std::getenv("YAHR_DEBUG_ASSUME_NESTED") && std::atoi(std::getenv("YAHR_DEBUG_ASSUME_NESTED")) != 0) d.boxes_finite |= 4;
   // bit 1: every triangle record small enough for the packet-level tri_far proof (device_math.hpp: tri_far_packet;
   // YAHR_NO_LEAF_CULL=1 switches the fat-leaf culling of the packet walker off: A/B measurements)
   {

@@ -65,7 +65,12 @@ enum {
  *   leaf     : b >= 0 = index of its first primitive record, a = number of primitives
  *              (a == 1: `wrapCollider col bb`, Culling.hs:33;  a > 1: multiLeaf, Culling.hs:52-54;
  *               a == 0: the null collider of Culling.hs:32, box = AABBs.empty)
- * lo/hi = BoundingBox min/max (AABBs.hs:8). */
+ * lo/hi = BoundingBox min/max (AABBs.hs:8).
+ * Any boxes are rendered with the reference's semantics.  Two properties every tree of Culling.hs:27-54 has are CHECKED
+ * when a context is created, and the packet walker's shortcuts are taken only where they hold: all boxes finite with
+ * lo <= hi (NaN-free slab test), and every child's box inside its parent's (Culling.hs:39: a parent's box is the join of
+ * its children's -- then a ray that fails a node fails everything below it, and the walk keeps no per-ray memory of the
+ * subtrees a ray has left). */
 typedef struct yahr_node {
   float lo[3]; int32_t a;
   float hi[3]; int32_t b;

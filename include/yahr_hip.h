@@ -293,6 +293,11 @@ void yahr_debug_fail_alloc(int32_t nth);
  * not finite, or a node's box is not exactly the join of its children's) and copies at most `cap` of them to `out`;
  * *levels = entries of the per-lane stack (depth of the deepest node). */
 int32_t yahr_debug_pair_records(const yahr_scene *scene, yahr_node *out, int32_t cap, int32_t *levels);
+/* Test hook: the device's `**` on Float (BSDF.hs:25) -- glibc's powf restated (yahr_amd/csrc/device_math.hpp: glibc_powf) --
+ * evaluated on `device` for n host operand pairs; the tests compare it with the host C library's powf bit for bit. */
+int yahr_debug_powf(int device, int32_t n, const float *x, const float *y, float *out);
+/* ... and the same source compiled for the host (no GPU needed). */
+int yahr_debug_powf_host(int32_t n, const float *x, const float *y, float *out);
 
 /* Upload a flattened scene to `device` (index as seen by this process).  The context owns device memory. */
 int yahr_ctx_create(const yahr_scene *scene, int device, yahr_ctx **out);

@@ -841,6 +841,12 @@ int oracle_scene_reachable(oscene *s, const float p0[3], const float p1[3]) {
   octx cx; memset(&cx, 0, sizeof cx);
   return reachable(s, ld3(p0), ld3(p1), &cx);
 }
+/* `**` on Float (BSDF.hs:25) is the C library's powf: this is the very call the restatement above makes, on arrays -- the
+ * tests hold the device's restatement of glibc's routine (yahr_amd/csrc/device_math.hpp: glibc_powf) against it. */
+void oracle_powf_array(int n, const float *x, const float *y, float *out) {
+  for (int i = 0; i < n; ++i) out[i] = powf(x[i], y[i]);
+}
+
 void oracle_radiance(oscene *s, const float x0[3], const float u[3], float tmax, float out[3]) {
   if (!s->built) oracle_scene_build(s);
   oray r; r.x0 = ld3(x0); r.u = ld3(u); r.tmax = tmax; octx cx; memset(&cx, 0, sizeof cx);

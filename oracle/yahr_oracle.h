@@ -91,6 +91,7 @@ void oracle_box_join(const float amin[3], const float amax[3], const float bmin[
                      float omin[3], float omax[3]);
 void oracle_box_centroid(const float bmin[3], const float bmax[3], float out[3]);
 float oracle_box_surf(const float bmin[3], const float bmax[3]);
+void oracle_powf_array(int n, const float *x, const float *y, float *out);   /* libm powf, elementwise */
 int oracle_bb_ray(const float bmin[3], const float bmax[3], const float x0[3], const float u[3],
                   float tmax, float *tnear);                                /* AABBs.hs:29-40 */
 /* Rays.hs:39-46 with constant colliders: is_hit[i] ? Just (Hit ts[i] _ i) : Nothing. Returns `what` or -1 */

@@ -72,6 +72,7 @@ def lib():
             "oracle_tree_dump": (C.c_int, [C.c_void_p, _I, _F, _I, _I, _I, _I]),
             "oracle_collide_triangle": (C.c_int, [_F] * 8 + [C.c_float] + [_F] * 5),
             "oracle_bb_ray": (C.c_int, [_F, _F, _F, _F, C.c_float, _F]),
+            "oracle_powf_array": (None, [C.c_int, _F, _F, _F]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)

@@ -3,8 +3,11 @@
 Bar (BASELINE.json north_star): every pixel within 1e-4 relative.  What is actually achieved and asserted:
   * hit/miss decisions, closest-hit identity, ray counts and (with first-hit shadow counting in the oracle)
     box / triangle / sphere test counts are EXACTLY those of the oracle;
-  * pixel values are bit-identical except where the Blinn term's `**` (powf) differs by an ulp between
-    glibc and the device library: |gpu - cpu| <= 1e-4 * max(|gpu|,|cpu|) + 1e-6 per channel (TOL below).
+  * pixel values are the oracle's BIT FOR BIT since round 4: the one inexact piece -- the Blinn term's `**`, the C library's
+    powf -- is glibc's routine restated on the device (device_math.hpp: glibc_powf, test_powf_is_the_hosts), so
+    assert_parity asks for |gpu - cpu| <= 1e-4 * max(|gpu|,|cpu|) + 1e-6 per channel (TOL below, the north star's bar)
+    AND for at least 9 999 pixels in 10 000 to be identical (all of them are, on hosts whose C library runs the routine's
+    FMA build).
 At BASELINE.json's full sizes (1920x1080, ~70k triangles) the checks are size-independent properties:
 idempotence, walker-independence, tile-decomposition independence, shard assembly, exact linearity in the
 light spectrum (scaling by a power of two), plus oracle parity (the oracle finishes 1080p in seconds)."""
@@ -68,6 +71,11 @@ def assert_parity(desc, modes=MODES, spp=1, seed=0, **kw):
     for m in modes:
         img, st = gpu_render(desc, traverse=m, spp=spp, seed=seed, **kw)
         assert outside_tol(img, ref) == 0, f"mode {m}"
+        # ... and since `**` is glibc's routine on the device too (device_math.hpp: glibc_powf) the image IS the oracle's,
+        # bit for bit (a NaN for a NaN).  One pixel in 10 000 is left to a host whose C library would run the routine's
+        # unfused build (no FMA: one powf in 10^8 then differs in its last bit) -- none differs on the machines used here.
+        same = ((bits(img) == bits(ref)) | (np.isnan(img) & np.isnan(ref))).all(axis=2)
+        assert same.mean() >= 0.9999, (f"mode {m}", int((~same).sum()))
         for k in ("primary_rays", "reflection_rays", "shadow_rays", "shaded_hits", "box_tests", "tri_tests", "sphere_tests"):
             assert st[k] == ost[k], (k, st[k], ost[k], m)
         assert st["tri_cull_violations"] == 0, m               # the fat-leaf culling's self-check (yahr_hip.h)
@@ -81,7 +89,7 @@ def assert_parity(desc, modes=MODES, spp=1, seed=0, **kw):
 # ---- configs[0] / [1] and small scenes ---------------------------------------------------------------
 def test_scene_fixed_256(gpu):
     img, ref = assert_parity(scenes.scene_fixed(256, 256))
-    assert (bits(img) == bits(ref)).all(axis=2).mean() > 0.95         # most pixels are bit-identical
+    assert (bits(img) == bits(ref)).all()                               # the oracle's image, bit for bit
     assert img.max() > 0.1
 
 
@@ -933,6 +941,24 @@ def test_extreme_scene_renders_the_same_in_all_forms(gpu):
                 assert np.array_equal(bits(img), bits(ref)), (bvh_depth, spp, m)
                 for k in COUNT_KEYS:
                     assert st0[k] == st1[k], (k, bvh_depth, spp, m)
+
+
+def test_powf_is_the_hosts(gpu):
+    """`**` on Float (BSDF.hs:25): the DEVICE's evaluation of glibc's powf restated (device_math.hpp: glibc_powf) against the
+    C library's own powf as the oracle calls it -- bit for bit on 4 M random / raw-bit-pattern operand pairs, on every
+    special case of the routine's front end, and on EVERY binary32 cosine in [1/16, 1] for two shininess values (the
+    operands of the Blinn term: 2 x 33.5 M).  tests/test_powf.py holds the same source, compiled for the host, to the same
+    standard without a GPU."""
+    from test_powf import libm_powf, powf_operands, same_floats, special_operands, _fp
+    from yahr_amd._lib import lib as L
+    sweep = np.arange(np.float32(0.0625).view(np.uint32), np.float32(1.0).view(np.uint32) + 1, dtype=np.uint32).view(np.float32)
+    cases = [powf_operands(4_000_000, 11), special_operands()] + [(sweep, np.full(len(sweep), e, np.float32)) for e in (10.0, 50.0)]
+    for x, y in cases:
+        ref = libm_powf(x, y)
+        got = np.zeros(len(x), np.float32)
+        assert L.yahr_debug_powf(0, len(x), _fp(x), _fp(y), _fp(got)) == 0
+        bad = np.flatnonzero(~same_floats(ref, got))
+        assert len(bad) == 0, (len(bad), [(hex(x[j].view(np.uint32)), hex(y[j].view(np.uint32)), ref[j], got[j]) for j in bad[:8]])
 
 
 def test_octant_run_only_on_nested_boxes(gpu, monkeypatch):

@@ -957,6 +957,28 @@ int yahr_ctx_camera_rays(yahr_ctx *c, int32_t n, const float *uv, float *rays) {
   return YAHR_OK;
 }
 
+int yahr_debug_powf(int device, int32_t n, const float *x, const float *y, float *out) {
+  if (n < 0 || (n && (!x || !y || !out))) { set_error("bad arguments"); return YAHR_E_ARG; }
+  if (n == 0) return YAHR_OK;
+  HIP_TRY(hipSetDevice(device));
+  DevMem d_x, d_y, d_o;
+  HIP_TRY(d_x.alloc(sizeof(float) * (size_t)n));
+  HIP_TRY(d_y.alloc(sizeof(float) * (size_t)n));
+  HIP_TRY(d_o.alloc(sizeof(float) * (size_t)n));
+  HIP_TRY(hipMemcpy(d_x.p, x, sizeof(float) * (size_t)n, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_y.p, y, sizeof(float) * (size_t)n, hipMemcpyHostToDevice));
+  HIP_TRY(yahr_dev::launch_debug_powf(n, d_x.as<float>(), d_y.as<float>(), d_o.as<float>(), nullptr));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out, d_o.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
+  return YAHR_OK;
+}
+
+int yahr_debug_powf_host(int32_t n, const float *x, const float *y, float *out) {
+  if (n < 0 || (n && (!x || !y || !out))) { set_error("bad arguments"); return YAHR_E_ARG; }
+  yahr_dev::debug_powf_host(n, x, y, out);
+  return YAHR_OK;
+}
+
 int yahr_render_rows(const yahr_scene *scene, int32_t row0, int32_t row1, int device,
                      const yahr_render_opts *opts, float *rgb_out, yahr_stats *stats) {
   if (!rgb_out) { set_error("null output"); return YAHR_E_ARG; }

@@ -1835,6 +1835,19 @@ hipError_t launch_warmup(hipStream_t st) {
   return hipGetLastError();
 }
 
+// test hook: device_math.hpp's glibc_powf on arrays (tests/test_gpu_parity.py compares it with the host's powf)
+__global__ void k_debug_powf(int n, const float *__restrict__ x, const float *__restrict__ y, float *__restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = glibc_powf(x[i], y[i]);
+}
+void debug_powf_host(int n, const float *x, const float *y, float *out) {       // the same source, compiled for the host
+  for (int i = 0; i < n; ++i) out[i] = glibc_powf(x[i], y[i]);
+}
+hipError_t launch_debug_powf(int n, const float *x, const float *y, float *out, hipStream_t st) {
+  hipLaunchKernelGGL(k_debug_powf, dim3((n + 255) / 256), dim3(256), 0, st, n, x, y, out);
+  return hipGetLastError();
+}
+
 hipError_t launch_camera_rays(const DScene &sc, int n, const float *uv, float *rays, hipStream_t st) {
   hipLaunchKernelGGL(k_camera_rays, dim3((n + 255) / 256), dim3(256), 0, st, sc, n, uv, rays);
   return hipGetLastError();

@@ -133,6 +133,8 @@ hipError_t launch_radiance(const DScene &sc, int mode, int n, const float *rays,
                            unsigned long long *ctr, float *lvl_spill, int lds_levels, hipStream_t st);
 hipError_t launch_warmup(hipStream_t st);          // an empty kernel: makes the runtime load this library's code object
 hipError_t launch_camera_rays(const DScene &sc, int n, const float *uv, float *rays, hipStream_t st);
+hipError_t launch_debug_powf(int n, const float *x, const float *y, float *out, hipStream_t st);   // test hook (device_math.hpp: glibc_powf)
+void debug_powf_host(int n, const float *x, const float *y, float *out);                              // ... compiled for the host
 // stream form: one pass = primary + depth level launches + resolve, all on `st`; sp.count must be zeroed by the caller
 hipError_t launch_stream_pass(const DScene &sc, const DPairs &dp, const RParams &rp, SParams sp, int secondary_mode, int n_blocks, float *out,
                               unsigned long long *ctr, bool stats, hipStream_t st);

@@ -183,14 +183,18 @@ def test_fat_leaf_culling_code(asm):
     launches of the wavefront form are built without it and touch no scratch memory inside their loops"""
     body = kernel_body(asm, PACKET_FAST)
     assert len(re.findall(r"v_min_f32_dpp", body)) == 6 * 36 and len(re.findall(r"v_max_f32_dpp", body)) == 6 * 36
-    # (two registers are parked in scratch memory at the kernel's entry and fetched after its last loop; nothing inside one)
+    # (at 64 registers the level kernels park ten of them in scratch memory around the shading of a hit -- the binary64
+    # evaluation of `**` (device_math.hpp: glibc_powf) is what tipped it: +0.5 % on the 1 M-triangle scene, DESIGN §5 -- at
+    # the kernel's entry, after its last loop and in the loop over the lights; the traversal loops hold one reload)
     m = meta(asm, STREAM_LEVEL)
-    assert m["vgpr_spill_count"] <= 4 and m["private_segment_fixed_size"] <= 16, m
-    label, note = "entry", ""
+    assert m["vgpr_spill_count"] <= 16 and m["private_segment_fixed_size"] <= 48, m
+    label, note, deep = "entry", "", 0
     for line in whole_body(asm, STREAM_LEVEL).split("\n"):
         lm = re.match(r"^(\.L\w+):\s*(;.*)?$", line)
         if lm:
             label, note = lm.group(1), lm.group(2) or ""
-        elif "scratch_" in line:
-            assert "Loop" not in note, (label, note, line)
+        elif "scratch_" in line and re.search(r"Depth=([2-9])", note):
+            assert "scratch_load" in line, (label, note, line)
+            deep += 1
+    assert deep <= 2, deep
     assert "v_min_f32_dpp" not in whole_body(asm, STREAM_LEVEL)

@@ -306,6 +306,19 @@ YHD int pow_checkint(unsigned iy) {                       // 0: not an integer, 
 }
 YHD bool pow_zeroinfnan(unsigned ix) { return 2u * ix - 1u >= 2u * 0x7f800000u - 1u; }
 YHD bool pow_signalling(unsigned ix) { return 2u * (ix ^ 0x00400000u) > 2u * 0x7fc00000u; }
+// (the six constants of the three product-sums that have two: a binary64 constant is a register pair on gfx950, v_fma_f64
+// takes one of them from scalar registers at most, and the compiler hoisted the vector copies out of the lights loop of the
+// 64-register level kernels and spilled them -- 25 registers to scratch memory.  Behind a volatile asm a constant is
+// formed where it is used: two v_mov)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define YD_POW_CONST(name, value)                                                                              \
+  unsigned name##_lo = (unsigned)(__builtin_bit_cast(unsigned long long, (double)(value)) & 0xffffffffu),       \
+           name##_hi = (unsigned)(__builtin_bit_cast(unsigned long long, (double)(value)) >> 32);               \
+  asm volatile("" : "+v"(name##_lo), "+v"(name##_hi));                                                         \
+  const double name = __builtin_bit_cast(double, ((unsigned long long)name##_hi << 32) | name##_lo)
+#else
+#define YD_POW_CONST(name, value) const double name = value
+#endif
 YHD float glibc_powf(float x, float y) {
   unsigned sign_bias = 0u;
   unsigned ix = __builtin_bit_cast(unsigned, x);
@@ -349,8 +362,10 @@ YHD float glibc_powf(float x, float y) {
   const double r = __builtin_fma(z, invc, -1.0);
   const double y0 = logc + (double)k;
   const double r2 = r * r;
-  double yy = __builtin_fma(0x1.27616c9496e0bp-2, r, -0x1.71969a075c67ap-2);
-  const double p = __builtin_fma(0x1.ec70a6ca7baddp-2, r, -0x1.7154748bef6c8p-1);
+  YD_POW_CONST(a1, -0x1.71969a075c67ap-2);
+  YD_POW_CONST(a3, -0x1.7154748bef6c8p-1);
+  double yy = __builtin_fma(0x1.27616c9496e0bp-2, r, a1);
+  const double p = __builtin_fma(0x1.ec70a6ca7baddp-2, r, a3);
   const double r4 = r2 * r2;
   double q = __builtin_fma(0x1.71547652ab82bp0, r, y0);
   q = __builtin_fma(p, r2, q);
@@ -368,7 +383,8 @@ YHD float glibc_powf(float x, float y) {
   unsigned long long t = yd_pow.exp2_tab[ki % 32u];
   t += (ki + sign_bias) << 47;
   const double sc = __builtin_bit_cast(double, t);
-  const double zz = __builtin_fma(0x1.c6af84b912394p-5, rr, 0x1.ebfce50fac4f3p-3);
+  YD_POW_CONST(c1, 0x1.ebfce50fac4f3p-3);
+  const double zz = __builtin_fma(0x1.c6af84b912394p-5, rr, c1);
   const double rr2 = rr * rr;
   double o = __builtin_fma(0x1.62e42ff0c52d6p-1, rr, 1.0);
   o = __builtin_fma(zz, rr2, o);
@@ -388,7 +404,11 @@ YD V3 loc_blinn(float e, V3 i, V3 o) {                                          
   float cos_o = fabsf(o.z), cos_i = fabsf(i.z);
   float cos_h = dot(i, h);
   float o_dot_h = dot(o, h);
+#ifdef YD_OCML_POWF                                                                   // (A/B measurements: HIP's own powf)
+  float d = ((e + 2.0f) * powf(fabsf(h.z), e)) / (2.0f * YD_PI);
+#else
   float d = ((e + 2.0f) * glibc_powf(fabsf(h.z), e)) / (2.0f * YD_PI);
+#endif
   float g = hmin(1.0f, hmin(((2.0f * cos_h) * cos_o) / o_dot_h, ((2.0f * cos_h) * cos_i) / o_dot_h));
   float f = 1.0f;                                                                    // fresnel, BSDF.hs:34
   return vof(((d * g) * f) / ((4.0f * cos_i) * cos_o));

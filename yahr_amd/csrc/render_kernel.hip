@@ -625,8 +625,8 @@ YD int packet_step(const DScene &sc, const NodeRec &cur, NodeRec &nxt, int i, V3
 // v_min3 nor the final `tnear > tfar` can see); for inv < 0 the other way round.  96.6 % of the pseudo-bunny's node
 // steps (99 % of the camera and shadow rays', 95 % of the reflection rays'; tools/oct_probe.py) belong to traversals
 // whose active lanes all look into the same octant: then WHICH plane is the near one is a property of the wavefront,
-// the six per-axis v_min / v_max (and the canonicalisation of tMax') disappear -- 29 -> 22 VALU per node step -- and the
-// choice costs no instruction at all if the walk is assembled once per octant: the near / far operands are just other
+// the six per-axis v_min / v_max (and the canonicalisation of tMax') disappear -- 29 -> 22 VALU per node step, 17 without
+// the sleep index, see below -- and the choice costs no instruction at all if the walk is assembled once per octant: the near / far operands are just other
 // SGPRs of the node record.
 // To keep the eight copies small they hold ONLY the walk from node to node: the run returns when some lane enters a
 // leaf, the leaf's primitives are handled by code that exists once (packet_leaf), and the run is entered again.
@@ -636,13 +636,25 @@ YD int packet_step(const DScene &sc, const NodeRec &cur, NodeRec &nxt, int i, V3
 // through its leaf hits) compiled to the 22 VALU but around them the compiler (a) sank the request for the next node
 // below the slab arithmetic, so that every step waited out a scalar-load round trip, and (b) funnelled the loop's exits
 // through flag registers, a dozen scalar instructions per step: 0.360 ms per pseudo-bunny frame against 0.330 without
-// the octant path.  In assembly the request goes out first, and a step is 22 VALU + 6-8 scalar instructions:
+// the octant path.  In assembly the request goes out first, and a step is 17 VALU + 6-8 scalar instructions:
 //     s_waitcnt lgkmcnt(0)                 current record (requested one step earlier) is here
 //     s_add / s_lshl / s_load_dwordx8      request node i + 1 into the OTHER record buffer
-//     v_cmp_ge_i32, v_cndmask              on = wake <= i;  tMax' = on ? tMax : -1
-//     6 v_sub, 6 v_mul, v_max (0), v_min (tMax'), v_max3, v_min3, v_cmp_ngt -> vcc = the lanes that enter the box
+//     6 v_sub, 6 v_mul, v_max (0), v_min (tMax), v_max3, v_min3, v_cmp_ngt -> vcc = the lanes that enter the box
 //     leaf:      vcc != 0 -> leave (index, count, first primitive, mask);  else on to i + 1
-//     interior:  wake = hit ? wake : max(wake, skip);  vcc != 0 -> i + 1 (already requested);  else request `skip`
+//     interior:  vcc != 0 -> i + 1 (already requested);  else request `skip`
+// NO SLEEP INDEX.  packet_loop keeps, per lane, the index at which the lane wakes up again (`wake`: the skip link of the
+// subtree it failed), hands sleeping lanes tMax' = -1 before every test and updates the index after it: 4 of 21 VALU in the
+// first form of this run.  It is redundant when every child's box lies inside its parent's: with lo_c >= lo_p, hi_c <= hi_p,
+// the same o and inv, monotone rounding gives per axis tnear_c >= tnear_p and tfar_c <= tfar_p (inv < 0: the planes swap
+// roles), tMax only shrinks during a traversal (a NaN tMax = "no limit" can only be replaced by a number), so a lane with
+// tnear_p > tfar_p has tnear_c >= tnear_p > tfar_p >= tfar_c: a ray that fails a node's box fails every box below it by
+// itself, and fails a leaf's joint box before any of its primitives is asked.  Nestedness holds in every tree Culling.hs:39
+// or this library builds (a parent's box is the join of its children's: no rounding) and is CHECKED per scene when a
+// context is created, because the node array is the caller's (abi_device.cpp: DScene.boxes_finite bit 2); trees that fail
+// keep packet_loop.  Lanes that take no part (inactive, or -- first-hit traversals -- finished) carry tMax = -1, which
+// fails every box.  What the sleep index also gave first-hit traversals -- a jump to the next node some lane still needs
+// when a lane finishes -- is gone: the nodes in between fail for every lane and leave by their skip links (~6 % more node
+// steps on the pseudo-bunny, at 17 instead of 21 VALU).
 // -- on the way from a node to its successor: s_waitcnt, s_add, s_lshl, s_load, s_cmp, two conditional branches that fall
 // through (and one s_branch every second step).
 // Two record buffers, the body written twice with their roles swapped (like packet_loop).  No bounds checks: the node
@@ -655,7 +667,7 @@ YD int packet_step(const DScene &sc, const NodeRec &cur, NodeRec &nxt, int i, V3
 // (low enough to be allocatable in every kernel: at 8 waves per SIMD the top of the SGPR file is reserved)
 // (an asm operand cannot name the components of a register tuple); the current record is copied in on entry, and the
 // statement drains its last request before it ends, so nothing lands in a register the compiler has taken back.
-// tMax' needs no canonicalisation here: traverse_packet hands over a canonical tMax (a quiet NaN stays "no limit":
+// tMax needs no canonicalisation here: traverse_packet hands over a canonical tMax (a quiet NaN stays "no limit":
 // v_min_f32 returns the other operand).
 // IDX = the register that holds the index of the node in this body, NXI = the one that receives IDX + 1: body A walks
 // node %[i] and puts i + 1 into %[nx], body B walks node %[nx] and puts nx + 1 into %[i] -- no register move on the way
@@ -729,7 +741,7 @@ YD int packet_step(const DScene &sc, const NodeRec &cur, NodeRec &nxt, int i, V3
 
 // Walks from node i (record `A`, arrived) until some lane enters a LEAF: returns the leaf's index, with its count and
 // first primitive in la / lb and the lanes that entered it in hm -- or an index >= n when the traversal is complete.
-// tMax cannot change in here (no primitive is tested), wake does.  OCT bit k set: inv component k is negative, the hi
+// tMax cannot change in here (no primitive is tested).  OCT bit k set: inv component k is negative, the hi
 // plane of that axis is the near one.
 template <int OCT>
 YD int oct_run(const float4 *base, int n, int i, const NodeRec &A, V3 o, V3 inv, float tmax, int &la, int &lb,

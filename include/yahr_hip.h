@@ -293,6 +293,10 @@ void yahr_debug_fail_alloc(int32_t nth);
  * not finite, or a node's box is not exactly the join of its children's) and copies at most `cap` of them to `out`;
  * *levels = entries of the per-lane stack (depth of the deepest node). */
 int32_t yahr_debug_pair_records(const yahr_scene *scene, yahr_node *out, int32_t cap, int32_t *levels);
+/* Test hook (host only): what a context would let the packet walker assume about this scene's arrays -- bit 0: every node
+ * box finite with lo <= hi; bit 2: ... and every child's box inside its parent's; bit 1: every triangle record's p0, e1, e2
+ * within +-2^32 (see yahr_node above).  Negative: an error code. */
+int32_t yahr_debug_box_flags(const yahr_scene *scene);
 /* Test hook: the device's `**` on Float (BSDF.hs:25) -- glibc's powf restated (yahr_amd/csrc/device_math.hpp: glibc_powf) --
  * evaluated on `device` for n host operand pairs; the tests compare it with the host C library's powf bit for bit. */
 int yahr_debug_powf(int device, int32_t n, const float *x, const float *y, float *out);

@@ -109,6 +109,7 @@ SIGNATURES = {
     "yahr_device_mem_info": (C.c_int, [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "yahr_debug_fail_alloc": (None, [C.c_int32]),
     "yahr_debug_pair_records": (C.c_int32, [C.POINTER(FlatScene), _VP, C.c_int32, C.POINTER(C.c_int32)]),
+    "yahr_debug_box_flags": (C.c_int32, [C.POINTER(FlatScene)]),
     "yahr_debug_powf": (C.c_int, [C.c_int, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "yahr_debug_powf_host": (C.c_int, [C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "yahr_debug_parallel_lists": (C.c_int32, []),

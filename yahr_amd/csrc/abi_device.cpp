@@ -303,6 +303,48 @@ int yahr_device_mem_info(int device, uint64_t *free_bytes, uint64_t *total_bytes
 }
 
 // Test hook (host only, no device needed): the child-pair records the stack walkers would get for this scene.
+// DScene.boxes_finite for a scene (render_kernel.hpp).  The node and primitive arrays are the caller's, so what the packet
+// walker's shortcuts rely on is checked here, once per context:
+//   bit 0  every node box finite with lo <= hi                     -> the NaN-free slab form (device_math.hpp: slab_hit_fast)
+//   bit 2  ... and every child's box inside its parent's (it is in every tree Culling.hs:39 or this library builds: a
+//          parent's box IS the join of its children's)            -> the octant run: a ray that failed a node's box fails
+//          every box below it, so lanes need no memory of the subtrees they left (render_kernel.hip: oct_run)
+//   bit 1  every triangle record's p0, e1, e2 within +-2^32       -> the packet-level tri_far proof (tri_far_packet)
+static int scene_box_flags(const yahr_scene *s) {
+  int flags = 1;
+  for (int32_t i = 0; i < s->n_nodes && flags; ++i)
+    for (int k = 0; k < 3; ++k)
+      if (!std::isfinite(s->nodes[i].lo[k]) || !std::isfinite(s->nodes[i].hi[k]) || !(s->nodes[i].lo[k] <= s->nodes[i].hi[k]))
+        flags = 0;
+  if (flags) {
+    bool nested = true;
+    for (int32_t i = 0; i + 2 < s->n_nodes && nested; ++i) {
+      const yahr_node &p = s->nodes[i];
+      if (p.b >= 0) continue;                                             // leaf
+      const int32_t l = i + 1, r = s->nodes[l].b < 0 ? s->nodes[l].a : l + 1;
+      if (r <= l || r >= s->n_nodes) { nested = false; break; }
+      for (int k = 0; k < 3; ++k)
+        if (!(s->nodes[l].lo[k] >= p.lo[k] && s->nodes[l].hi[k] <= p.hi[k] && s->nodes[r].lo[k] >= p.lo[k] && s->nodes[r].hi[k] <= p.hi[k]))
+          nested = false;
+    }
+    if (nested) flags |= 4;
+  }
+  bool bounded = true;
+  for (int32_t i = 0; i < s->n_prims && bounded; ++i) {
+    const yahr_prim &p = s->prims[i];
+    if (p.kind != 0) continue;
+    for (int k = 0; k < 3; ++k)
+      if (!(std::fabs(p.p0[k]) <= 4294967296.0f) || !(std::fabs(p.e1[k]) <= 4294967296.0f) || !(std::fabs(p.e2[k]) <= 4294967296.0f))
+        bounded = false;
+  }
+  if (bounded) flags |= 2;
+  return flags;
+}
+int32_t yahr_debug_box_flags(const yahr_scene *s) {
+  if (!s || (s->n_nodes && !s->nodes) || (s->n_prims && !s->prims)) { set_error("bad arguments"); return YAHR_E_ARG; }
+  return scene_box_flags(s);
+}
+
 int32_t yahr_debug_pair_records(const yahr_scene *s, yahr_node *out, int32_t cap, int32_t *levels) {
   if (levels) *levels = 0;
   if (!s || s->n_nodes < 0 || (s->n_nodes && !s->nodes)) return 0;
@@ -390,44 +432,14 @@ static int ctx_create_impl(const yahr_scene *s, int device, yahr_ctx **out, size
   d.n_nodes = s->n_nodes; d.n_prims = s->n_prims; d.n_mats = s->n_mats; d.n_lights = s->n_lights;
   d.depth = s->depth;
   { const AutoPolicy ap = auto_policy_for(s); c->auto_mode = ap.fused; c->auto_stream_min = ap.stream_min_samples; c->stream_secondary = ap.secondary; c->deep_thin = ap.deep_thin; }
-  d.boxes_finite = 1;
-  for (int32_t i = 0; i < s->n_nodes && d.boxes_finite; ++i)
-    for (int k = 0; k < 3; ++k)
-      if (!std::isfinite(s->nodes[i].lo[k]) || !std::isfinite(s->nodes[i].hi[k]) || !(s->nodes[i].lo[k] <= s->nodes[i].hi[k]))
-        d.boxes_finite = 0;
-  // bit 2: every child's box lies inside its parent's (it does in every tree Culling.hs:39 or this library builds -- a
-  // parent's box IS the join of its children's -- but the node array is the caller's).  The octant run of the packet walker
-  // relies on it: a ray that failed a node's box then fails every box below it (render_kernel.hip), so lanes need no
-  // memory of the subtrees they left.  YAHR_NO_NESTED=1 clears the bit (A/B measurements, tests).
-  if (d.boxes_finite && !(std::getenv("YAHR_NO_NESTED") && std::atoi(std::getenv("YAHR_NO_NESTED")) != 0)) {
-    bool nested = true;
-    for (int32_t i = 0; i + 2 < s->n_nodes && nested; ++i) {
-      const yahr_node &p = s->nodes[i];
-      if (p.b != -1) continue;                                            // leaf
-      const int32_t l = i + 1, r = s->nodes[l].b == -1 ? s->nodes[l].a : l + 1;
-      if (r <= l || r >= s->n_nodes) { nested = false; break; }
-      for (int k = 0; k < 3; ++k)
-        if (!(s->nodes[l].lo[k] >= p.lo[k] && s->nodes[l].hi[k] <= p.hi[k] && s->nodes[r].lo[k] >= p.lo[k] && s->nodes[r].hi[k] <= p.hi[k]))
-          nested = false;
-    }
-    if (nested) d.boxes_finite |= 4;
-  }
-  // (test hook: claim nestedness unchecked -- tests/test_gpu_parity.py shows with it that the check above is what keeps the
+  // what the packet walker's shortcuts may assume about this scene (scene_box_flags), minus what the environment switches off
+  d.boxes_finite = scene_box_flags(s);
+  // YAHR_NO_NESTED=1 / YAHR_NO_LEAF_CULL=1: A/B measurements and tests (results are identical either way)
+  if (std::getenv("YAHR_NO_NESTED") && std::atoi(std::getenv("YAHR_NO_NESTED")) != 0) d.boxes_finite &= ~4;
+  if (std::getenv("YAHR_NO_LEAF_CULL") && std::atoi(std::getenv("YAHR_NO_LEAF_CULL")) != 0) d.boxes_finite &= ~2;
+  // (test hook: claim nestedness unchecked -- tests/test_gpu_parity.py shows with it that the check is what keeps the
   // octant run off trees it would walk wrongly)
-  if (d.boxes_finite && std::getenv("YAHR_DEBUG_ASSUME_NESTED") && std::atoi(std::getenv("YAHR_DEBUG_ASSUME_NESTED")) != 0) d.boxes_finite |= 4;
-  // bit 1: every triangle record small enough for the packet-level tri_far proof (device_math.hpp: tri_far_packet;
-  // YAHR_NO_LEAF_CULL=1 switches the fat-leaf culling of the packet walker off: A/B measurements)
-  {
-    bool bounded = !(std::getenv("YAHR_NO_LEAF_CULL") && std::atoi(std::getenv("YAHR_NO_LEAF_CULL")) != 0);
-    for (int32_t i = 0; i < s->n_prims && bounded; ++i) {
-      const yahr_prim &p = s->prims[i];
-      if (p.kind != 0) continue;
-      for (int k = 0; k < 3; ++k)
-        if (!(std::fabs(p.p0[k]) <= 4294967296.0f) || !(std::fabs(p.e1[k]) <= 4294967296.0f) || !(std::fabs(p.e2[k]) <= 4294967296.0f))
-          bounded = false;
-    }
-    if (bounded) d.boxes_finite |= 2;
-  }
+  if ((d.boxes_finite & 1) && std::getenv("YAHR_DEBUG_ASSUME_NESTED") && std::atoi(std::getenv("YAHR_DEBUG_ASSUME_NESTED")) != 0) d.boxes_finite |= 4;
   // Is the wavefront form a candidate at all?  Then ask the scene how coherent its rays are: a probe render (four strips
   // of 8 rows of the scene camera's frame, 1 spp, packet walker, counted build) yields the lane utilisation of the packet
   // walker's node steps = box tests / (64 x wavefront node steps).  Triangle soups -- where compaction between bounces

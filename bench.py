@@ -242,7 +242,7 @@ def main():
     ap.add_argument("--workload", default="bunny", choices=sorted(WORKLOADS))
     ap.add_argument("--traverse", default="auto", choices=["auto", "lane", "packet", "hybrid", "stream", "stack", "hybrid_stack", "ordered"])
     ap.add_argument("--strip-rows", type=int, default=8)
-    ap.add_argument("--frames-per-launch", type=int, default=8, help="per rank; a launch holds this x ranks frames")
+    ap.add_argument("--frames-per-launch", type=int, default=20, help="per rank; a launch holds this x ranks frames")
     ap.add_argument("--repeats", type=int, default=0, help="repeats of the K-step block inside the timed region; 0 = "
                                                            "as many as make the region last --min-seconds")
     ap.add_argument("--min-seconds", type=float, default=3.0)
@@ -285,8 +285,10 @@ def main():
     trav = {"auto": yahr_amd.TRAVERSE_AUTO, "lane": yahr_amd.TRAVERSE_LANE, "packet": yahr_amd.TRAVERSE_PACKET,
             "hybrid": yahr_amd.TRAVERSE_HYBRID, "stream": yahr_amd.TRAVERSE_STREAM, "stack": yahr_amd.TRAVERSE_STACK,
             "hybrid_stack": yahr_amd.TRAVERSE_HYBRID_STACK, "ordered": yahr_amd.TRAVERSE_ORDERED}[args.traverse]
-    # frames per launch: 8 per rank (every rank then gets as many tiles per launch as in the 1-GPU case, so the
-    # per-launch tail stays amortised and the gathers get larger and fewer), never more than K
+    # frames per launch: 20 per rank (every rank then gets as many tiles per launch as in the 1-GPU case, so the
+    # per-launch tail stays amortised and the gathers get larger and fewer), never more than K.  (8 until the second half
+    # of round 4: with the shorter kernel the fixed ~0.15 ms per launch weighs more -- 8 / 16 / 20 / 25 / 40 distinct
+    # cameras per launch: 0.2742 / 0.2707 / 0.2664 / 0.2655 / 0.2657 ms per frame, profiles/r04_frames_per_launch.txt)
     F = max(1, min(args.frames_per_launch * world, K))
     n_full, f_tail = K // F, K % F
     if not args.same_camera:

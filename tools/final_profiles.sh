@@ -9,8 +9,8 @@ tools/profile_bench.sh ${R}_spheres --workload spheres --steps 200 --warmup 24 >
 YAHR_SPILL_BUDGET_KB=120000000 tools/profile_bench.sh ${R}_bunny4k --workload bunny4k --steps 2 --warmup 2 --frames-per-launch 2 > gpurun_out/prof_${R}_bunny4k.log 2>&1
 tools/profile_bench.sh ${R}_tris1m --workload tris1m --steps 8 --warmup 8 > gpurun_out/prof_${R}_tris1m.log 2>&1
 SRC="rocprofv3 --pmc passes (one counter group per pass, tools/profile_bench.sh) of bench.py --workload %s --no-cpu-baseline --repeats 2 on one MI355X (profiles/${R}_%s_pmc_summary.txt)"
-python3 tools/pmc_to_traffic.py gpurun_out/prof_${R}_bunny/pmc_summary.txt bunny 8 "$(printf "$SRC" bunny bunny)" > gpurun_out/traffic_latest.json
-python3 tools/pmc_to_traffic.py gpurun_out/prof_${R}_spheres/pmc_summary.txt spheres 8 "$(printf "$SRC" spheres spheres)" > gpurun_out/traffic_spheres.json
+python3 tools/pmc_to_traffic.py gpurun_out/prof_${R}_bunny/pmc_summary.txt bunny 20 "$(printf "$SRC" bunny bunny)" > gpurun_out/traffic_latest.json
+python3 tools/pmc_to_traffic.py gpurun_out/prof_${R}_spheres/pmc_summary.txt spheres 20 "$(printf "$SRC" spheres spheres)" > gpurun_out/traffic_spheres.json
 python3 tools/pmc_to_traffic.py gpurun_out/prof_${R}_bunny4k/pmc_summary.txt bunny4k 2 "$(printf "$SRC" bunny4k bunny4k)" > gpurun_out/traffic_bunny4k.json
 python3 tools/pmc_to_traffic.py gpurun_out/prof_${R}_tris1m/pmc_summary.txt tris1m 8 "$(printf "$SRC" tris1m tris1m)" 2 > gpurun_out/traffic_tris1m.json
 for w in bunny spheres bunny4k tris1m; do

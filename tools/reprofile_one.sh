@@ -2,8 +2,8 @@
 # re-profile ONE workload and refresh its traffic json + bench line (see final_profiles.sh).  usage: reprofile_one.sh <round> <workload>
 R=$1; W=$2; cd /root/repo
 case $W in
-  bunny) tools/profile_bench.sh ${R}_bunny --steps 200 --warmup 24 > gpurun_out/prof_${R}_bunny.log 2>&1; F=8; D=; OUT=traffic_latest.json;;
-  spheres) tools/profile_bench.sh ${R}_spheres --workload spheres --steps 200 --warmup 24 > gpurun_out/prof_${R}_spheres.log 2>&1; F=8; D=; OUT=traffic_spheres.json;;
+  bunny) tools/profile_bench.sh ${R}_bunny --steps 200 --warmup 24 > gpurun_out/prof_${R}_bunny.log 2>&1; F=20; D=; OUT=traffic_latest.json;;
+  spheres) tools/profile_bench.sh ${R}_spheres --workload spheres --steps 200 --warmup 24 > gpurun_out/prof_${R}_spheres.log 2>&1; F=20; D=; OUT=traffic_spheres.json;;
   bunny4k) YAHR_SPILL_BUDGET_KB=120000000 tools/profile_bench.sh ${R}_bunny4k --workload bunny4k --steps 2 --warmup 2 --frames-per-launch 2 > gpurun_out/prof_${R}_bunny4k.log 2>&1; F=2; D=; OUT=traffic_bunny4k.json;;
   tris1m) tools/profile_bench.sh ${R}_tris1m --workload tris1m --steps 8 --warmup 8 > gpurun_out/prof_${R}_tris1m.log 2>&1; F=8; D=2; OUT=traffic_tris1m.json;;
 esac

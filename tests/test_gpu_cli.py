@@ -56,3 +56,31 @@ def test_stale_scene_needs_lenient_flag(gpu, tmp_path):
     env = dict(os.environ, YAHR_LENIENT="1")
     assert subprocess.run([YAHR, str(src), str(out)], capture_output=True, env=env).returncode == 0
     assert os.stat(out).st_size == len(b"P6\n8 6\n255\n") + 8 * 6 * 3
+
+
+def test_bench_line_contract(gpu):
+    """`python bench.py --gpus 1 --steps K --warmup W` (the driver's command shape) prints ONE JSON line with the contract's
+    fields, the `roofline` and `cpu_baseline` objects, and a same-run `parity` object that holds every compared pixel of the
+    timed batch's first frame identical to the oracle's."""
+    import json
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "8", "--warmup", "2", "--min-seconds", "0.3"],
+                       capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "parity", "single_frame_ms", "gather_ms_avg", "gather_exposed_ms_avg"):
+        assert k in d, k
+    assert d["unit"] == "Mrays/s" and d["n_gpus"] == 1 and d["steps"] == 8 and d["warmup"] == 2 and d["higher_is_better"] is True
+    assert d["value"] > 1000 and abs(d["ms_per_step"] * d["value"] * 1e3 / d["config"]["rays_per_frame"] - 1.0) < 0.02
+    assert "workload" in d["config"] and d["config"]["frames_per_launch"] == 8 and d["vs_baseline"] is None and d["dtype"] == "f32"
+    rf = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "survey_8d_frac", "kernel_ms_avg", "profile_matches_source"):
+        assert k in rf, k
+    assert rf["profile_matches_source"] is True and 0.3 < rf["frac"] < 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 1 and cb["cores"] >= 1 and cb["unit"] == "Mrays/s" and cb["sample"]
+    pa = d["parity"]
+    assert pa["pixels"] == 1920 * 1080 and pa["pixels_outside_tolerance"] == 0 and pa["bit_identical_pixels"] >= 0.9999 * pa["pixels"]
